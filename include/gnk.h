@@ -1,0 +1,132 @@
+/*
+ * gnk.h -- C ABI of libgnk_hip.so: the MI355X (gfx950) kernels behind the gn_kernels operator
+ * library and the quantized-training tensor subclasses.
+ *
+ * Conventions (all entry points):
+ *   - raw DEVICE pointers, int64 dims and strides in ELEMENTS, dtype codes from gnk_dtype;
+ *   - inputs are borrowed and never written; outputs are caller-allocated, row-major contiguous
+ *     (M, N) unless strides are given; nothing is allocated or freed, nothing synchronises;
+ *   - `stream` is a hipStream_t (NULL = default stream); launches are asynchronous;
+ *   - return value 0 on success, a negative gnk_status otherwise; gnk_last_error() returns a
+ *     thread-local message for the last failure on the calling thread.
+ *
+ * Citations are paths inside the reference repository (gau-nernst/quantized-training).
+ */
+#ifndef GNK_H
+#define GNK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gnk_dtype {
+    GNK_BF16 = 0,
+    GNK_F16 = 1,
+    GNK_F32 = 2,
+    GNK_I8 = 3,
+    GNK_E4M3 = 4, /* OCP float8_e4m3fn */
+    GNK_E5M2 = 5, /* OCP float8_e5m2   */
+    GNK_I32 = 6
+} gnk_dtype;
+
+typedef enum gnk_status {
+    GNK_OK = 0,
+    GNK_ERR_BAD_ARG = -1,     /* null pointer, negative size, unknown dtype code ...            */
+    GNK_ERR_UNSUPPORTED = -2, /* legal request this build has no kernel for                     */
+    GNK_ERR_LAUNCH = -3,      /* HIP reported an error at launch                                */
+    GNK_ERR_WORKSPACE = -4    /* a required workspace pointer was NULL or too small             */
+} gnk_status;
+
+/* Library identification; bumps when an entry point changes. */
+int gnk_abi_version(void);
+
+/* Message for the last non-zero status returned on this thread ("" if none). */
+const char *gnk_last_error(void);
+
+/* Optional one-time set-up for the current device (queries CU count).  Every entry point calls
+ * it lazily; exposed so that a host can pay the cost outside its timed region. */
+int gnk_init(void);
+
+/*
+ * Row-wise absmax symmetric INT8 quantization.
+ * Replaces: subclasses/int8.py:12-26 (quantize_int8), which the reference runs as ~9 eager ATen
+ * kernels or Inductor-generated Triton; here it is ONE pass (two for a strided reduction).
+ *
+ * x is a logical (R, C) matrix of x_dtype (BF16/F16/F32) with element strides (sxr, sxc); the
+ * absmax runs over C for every r (the caller maps `dim` onto this by swapping strides).
+ *   scale[r] = amax_c |x[r,c]| / 127            (fp32, true division), stored as x_dtype
+ *   q[r,c]   = clip(round_half_even(x[r,c] / max(scale[r], eps)), -128, 127)
+ * q has strides (sqr, sqc).  sr != 0 replaces the rounding by floor(v + u), u ~ U[0,1) from
+ * Philox4x32-10 keyed by (seed, offset) and indexed by the logical element number r*C + c.
+ * workspace: device buffer of >= R floats, needed only when the reduction runs along the strided
+ * dimension (sxc != 1); may be NULL otherwise.  gnk_quantize_int8_workspace_bytes() tells.
+ */
+int gnk_quantize_int8(const void *x, int x_dtype, int64_t R, int64_t C, int64_t sxr, int64_t sxc,
+                      int8_t *q, int64_t sqr, int64_t sqc, void *scale, float eps,
+                      int sr, uint64_t seed, uint64_t offset,
+                      void *workspace, int64_t workspace_bytes, void *stream);
+
+int64_t gnk_quantize_int8_workspace_bytes(int64_t R, int64_t C, int64_t sxr, int64_t sxc);
+
+/*
+ * C(int32, M x N) = A(int8, M x K) @ B(int8, K x N), exact.
+ * Replaces: kernels/gn_kernels/triton_mm.py:112-143 (int8_mm -> _triton_mm -> _matmul_kernel
+ * :53-109 with ACC_DTYPE=int32).  Any strides; the three layouts of benchmark_mm.py:33-34,91-96
+ * (A@B.T, A@B, A.T@B) take the MFMA fast path without materialising a transpose.
+ */
+int gnk_int8_mm(const int8_t *A, const int8_t *B, int32_t *C, int64_t M, int64_t N, int64_t K,
+                int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, void *stream);
+
+/*
+ * Row/column-scaled low-precision GEMM with fused epilogue:
+ *   order 0:  C[m,n] = cast_out( (f32(acc[m,n]) * row_scale[m]) * col_scale[n] )
+ *   order 1:  C[m,n] = cast_out( (f32(acc[m,n]) * col_scale[n]) * row_scale[m] )
+ * acc is int32 (exact) for I8 operands and fp32 for E4M3/E5M2 operands (the two fp8 formats may
+ * be mixed).  col_scale is one scalar when col_scale_is_scalar != 0.  Scales are scale_dtype
+ * (BF16/F16/F32), contiguous; C is out_dtype (BF16/F16/F32), row-major contiguous.
+ * Replaces: triton_mm.py:382-407 (scaled_mm CUDA impl -> _scaled_mm_kernel :146-220), order 0;
+ *           kernels/csrc/cutlass_sm89_fp8.cu:62-185 (scaled_fp8_mm), order 1;
+ *           kernels/csrc/cutlass_sm120a_fp8.cu:106-217 (cutlass_scaled_fp8_mm), order 1.
+ */
+int gnk_scaled_mm(const void *A, int a_dtype, const void *B, int b_dtype, void *C, int out_dtype,
+                  const void *row_scale, const void *col_scale, int scale_dtype,
+                  int col_scale_is_scalar, int order, int64_t M, int64_t N, int64_t K,
+                  int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, void *stream);
+
+/*
+ * Tile-scaled (2-D block scale) GEMM: for ascending K-blocks kb of QK elements
+ *   acc_f32[m,n] += (f32(partial_kb[m,n]) * sA[m / QM, kb]) * sB[kb, n / QN]
+ * with a fresh int32 / fp32 partial accumulator per K-block; multiply, multiply, add are separate
+ * roundings (no FMA).  sA is (M/QM, K/QK) with strides (ssam, ssak); sB is (K/QK, N/QN) with
+ * strides (ssbk, ssbn); both scale_dtype.  C is out_dtype, row-major contiguous.
+ * Replaces: triton_mm.py:410-441 (tile_scaled_mm CUDA impl -> _tile_scaled_mm_kernel :223-342).
+ */
+int gnk_tile_scaled_mm(const void *A, int a_dtype, const void *B, int b_dtype, void *C, int out_dtype,
+                       const void *sA, const void *sB, int scale_dtype,
+                       int64_t M, int64_t N, int64_t K,
+                       int64_t sam, int64_t sak, int64_t sbk, int64_t sbn,
+                       int64_t ssam, int64_t ssak, int64_t ssbk, int64_t ssbn,
+                       int64_t QM, int64_t QN, int64_t QK, void *stream);
+
+/*
+ * Unscaled FP8 GEMM, fp32 accumulate, cast to out_dtype.
+ * Replaces: kernels/csrc/cutlass_sm89_fp8.cu:28-57 (fp8_mm), cutlass_sm120a_fp8.cu:35-104
+ * (cutlass_fp8_mm), and _triton_mm with fp8 inputs (triton_mm.py:131-143; benchmark_mm.py:129).
+ */
+int gnk_fp8_mm(const void *A, int a_dtype, const void *B, int b_dtype, void *C, int out_dtype,
+               int64_t M, int64_t N, int64_t K,
+               int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, void *stream);
+
+/*
+ * Test / tuning hook (no reference counterpart): force a GEMM kernel variant for subsequent
+ * calls on this thread.  variant < 0 restores the built-in heuristic.  Returns the previous
+ * value.  Variants are listed in csrc/gnk_gemm_dispatch.h.
+ */
+int gnk_set_gemm_variant(int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNK_H */

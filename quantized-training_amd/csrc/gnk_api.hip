@@ -1,0 +1,196 @@
+// gnk_api.hip -- extern "C" entry points of libgnk_hip.so (see include/gnk.h) and the host-side
+// dispatch between the LDS-DMA MFMA kernels and the generic fallback.
+#include "gnk_gemm_dispatch.h"
+
+#include <string.h>
+
+// ------------------------------------------------------------------ error plumbing
+static thread_local char g_err[512] = "";
+static thread_local int g_forced_variant = -1;
+
+int gnk_fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int gnk_check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return gnk_fail(GNK_ERR_LAUNCH, "%s: launch failed: %s", what, hipGetErrorString(e));
+    return GNK_OK;
+}
+
+static int g_cus[64];
+
+int gnk_num_cus(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (g_cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        g_cus[dev] = n;
+    }
+    return g_cus[dev];
+}
+
+extern "C" int gnk_abi_version(void) { return 1; }
+extern "C" const char *gnk_last_error(void) { return g_err; }
+
+extern "C" int gnk_init(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return gnk_fail(GNK_ERR_LAUNCH, "no HIP device is visible: libgnk_hip.so has no CPU path");
+    gnk_num_cus();
+    return GNK_OK;
+}
+
+extern "C" int gnk_set_gemm_variant(int variant) {
+    const int old = g_forced_variant;
+    g_forced_variant = variant;
+    return old;
+}
+
+// ------------------------------------------------------------------ GEMM dispatch
+namespace {
+
+struct OperandLayout {
+    bool fast;     // usable by the LDS-DMA kernels
+    bool kmajor;   // K contiguous (else M/N contiguous)
+    int64_t ld;
+};
+
+// ptr: operand base; ext: M or N; s_mn / s_k: element strides along M(N) and K.
+OperandLayout classify(const void *ptr, int64_t ext, int64_t K, int64_t s_mn, int64_t s_k) {
+    OperandLayout o = {false, true, 0};
+    if (((uintptr_t)ptr & 15) != 0) return o;
+    // K-major: every row is a contiguous K-vector starting at a 16-byte boundary
+    if (s_k == 1 && (ext == 1 || (s_mn % 16 == 0 && s_mn >= K))) {
+        o.fast = true; o.kmajor = true; o.ld = ext == 1 ? K : s_mn;
+        return o;
+    }
+    // M/N-major: every k is a contiguous M(N)-vector of a multiple of 16 elements
+    if (s_mn == 1 && ext >= 16 && ext % 16 == 0 && (K == 1 || (s_k % 16 == 0 && s_k >= ext))) {
+        o.fast = true; o.kmajor = false; o.ld = K == 1 ? ext : s_k;
+        return o;
+    }
+    return o;
+}
+
+gnk_gemm_launcher pick_launcher(int op, int fa, int fb, int variant) {
+    if (op == OP_I8) return variant == GNK_VARIANT_256 ? gnk_launch_i8_v0 : gnk_launch_i8_v1;
+    static const gnk_gemm_launcher f8[2][2][2] = {
+        {{gnk_launch_f8_00_v0, gnk_launch_f8_00_v1}, {gnk_launch_f8_01_v0, gnk_launch_f8_01_v1}},
+        {{gnk_launch_f8_10_v0, gnk_launch_f8_10_v1}, {gnk_launch_f8_11_v0, gnk_launch_f8_11_v1}}};
+    return f8[fa][fb][variant == GNK_VARIANT_256 ? 0 : 1];
+}
+
+struct GemmCall {
+    const void *A; int a_dtype; const void *B; int b_dtype; void *C; int out_dtype;
+    const void *s0; const void *s1; int scale_dtype; int col_scalar; int order; int epi;
+    int64_t M, N, K, sam, sak, sbk, sbn;
+    int64_t ssam, ssak, ssbk, ssbn, QM, QN, QK;
+};
+
+int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
+    if (c.M < 0 || c.N < 0 || c.K < 0) return gnk_fail(GNK_ERR_BAD_ARG, "%s: negative dimension", name);
+    const bool i8 = c.a_dtype == GNK_I8 && c.b_dtype == GNK_I8;
+    const bool f8 = gnk_is_f8(c.a_dtype) && gnk_is_f8(c.b_dtype);
+    if (!i8 && !f8) return gnk_fail(GNK_ERR_BAD_ARG, "%s: operands must be both int8 or both fp8 (got dtype codes %d, %d)", name, c.a_dtype, c.b_dtype);
+    if (c.M == 0 || c.N == 0) return GNK_OK;
+    if (!c.C || (c.K > 0 && (!c.A || !c.B))) return gnk_fail(GNK_ERR_BAD_ARG, "%s: null pointer", name);
+    if (c.epi != EPI_PLAIN) {
+        if (!c.s0 || !c.s1) return gnk_fail(GNK_ERR_BAD_ARG, "%s: null scale pointer", name);
+        if (!gnk_is_float_dtype(c.scale_dtype)) return gnk_fail(GNK_ERR_BAD_ARG, "%s: scale dtype code %d is not bf16/f16/f32", name, c.scale_dtype);
+    }
+    if (!(c.epi == EPI_PLAIN && i8) && !gnk_is_float_dtype(c.out_dtype))
+        return gnk_fail(GNK_ERR_BAD_ARG, "%s: output dtype code %d is not bf16/f16/f32", name, c.out_dtype);
+    if (c.epi == EPI_TILE && (c.QM <= 0 || c.QN <= 0 || c.QK <= 0)) return gnk_fail(GNK_ERR_BAD_ARG, "%s: non-positive scale block size", name);
+    int rc = gnk_init();
+    if (rc) return rc;
+
+    const int op = i8 ? OP_I8 : OP_F8;
+    const int fa = c.a_dtype == GNK_E5M2 ? F8_E5M2 : F8_E4M3, fb = c.b_dtype == GNK_E5M2 ? F8_E5M2 : F8_E4M3;
+
+    int variant = g_forced_variant;
+    const OperandLayout la = classify(c.A, c.M, c.K, c.sam, c.sak);
+    const OperandLayout lb = classify(c.B, c.N, c.K, c.sbn, c.sbk);
+    const bool fast_ok = la.fast && lb.fast && c.K >= GNK_BK && c.K % GNK_BK == 0 && (c.epi != EPI_TILE || c.QK == GNK_BK) &&
+                         c.M < (1LL << 31) && c.N < (1LL << 31) && ((c.M + 127) / 128) * ((c.N + 127) / 128) < (1LL << 31);
+    if (variant < 0 || variant > GNK_VARIANT_GENERIC) {
+        if (!fast_ok) variant = GNK_VARIANT_GENERIC;
+        else {
+            // 256^2 tiles once they alone fill most of the chip, else 128^2 (2 workgroups / CU)
+            const int64_t big_tiles = ((c.M + 255) / 256) * ((c.N + 255) / 256);
+            variant = (c.epi != EPI_TILE && big_tiles * 10 >= (int64_t)gnk_num_cus() * 8) ? GNK_VARIANT_256 : GNK_VARIANT_128;
+        }
+    } else if (variant != GNK_VARIANT_GENERIC && !fast_ok) {
+        return gnk_fail(GNK_ERR_UNSUPPORTED, "%s: forced fast variant %d cannot take these strides / sizes", name, variant);
+    }
+
+    if (variant == GNK_VARIANT_GENERIC) {
+        GenericParams g;
+        memset(&g, 0, sizeof(g));
+        g.A = (const char *)c.A; g.B = (const char *)c.B; g.C = c.C; g.s0 = c.s0; g.s1 = c.s1;
+        g.M = c.M; g.N = c.N; g.K = c.K; g.sam = c.sam; g.sak = c.sak; g.sbk = c.sbk; g.sbn = c.sbn;
+        g.ssam = c.ssam; g.ssak = c.ssak; g.ssbk = c.ssbk; g.ssbn = c.ssbn; g.QM = c.QM; g.QN = c.QN; g.QK = c.QK;
+        g.epi = c.epi; g.out_dtype = c.out_dtype; g.scale_dtype = c.scale_dtype; g.col_scalar = c.col_scalar; g.order = c.order;
+        return gnk_launch_generic(op, fa, fb, g, st);
+    }
+
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = (const char *)c.A; p.B = (const char *)c.B; p.C = c.C; p.s0 = c.s0; p.s1 = c.s1;
+    p.M = c.M; p.N = c.N; p.K = c.K; p.lda = la.ld; p.ldb = lb.ld;
+    p.ssam = c.ssam; p.ssak = c.ssak; p.ssbk = c.ssbk; p.ssbn = c.ssbn; p.QM = c.QM; p.QN = c.QN;
+    p.out_dtype = c.out_dtype; p.scale_dtype = c.scale_dtype; p.col_scalar = c.col_scalar; p.order = c.order;
+    return pick_launcher(op, fa, fb, variant)(la.kmajor, lb.kmajor, c.epi, p, st);
+}
+
+}  // namespace
+
+extern "C" int gnk_int8_mm(const int8_t *A, const int8_t *B, int32_t *C, int64_t M, int64_t N, int64_t K, int64_t sam,
+                           int64_t sak, int64_t sbk, int64_t sbn, void *stream) {
+    GemmCall c;
+    memset(&c, 0, sizeof(c));
+    c.A = A; c.a_dtype = GNK_I8; c.B = B; c.b_dtype = GNK_I8; c.C = C; c.out_dtype = GNK_I32; c.epi = EPI_PLAIN;
+    c.M = M; c.N = N; c.K = K; c.sam = sam; c.sak = sak; c.sbk = sbk; c.sbn = sbn;
+    return run_gemm("int8_mm", c, (hipStream_t)stream);
+}
+
+extern "C" int gnk_scaled_mm(const void *A, int a_dtype, const void *B, int b_dtype, void *C, int out_dtype,
+                             const void *row_scale, const void *col_scale, int scale_dtype, int col_scale_is_scalar,
+                             int order, int64_t M, int64_t N, int64_t K, int64_t sam, int64_t sak, int64_t sbk,
+                             int64_t sbn, void *stream) {
+    GemmCall c;
+    memset(&c, 0, sizeof(c));
+    c.A = A; c.a_dtype = a_dtype; c.B = B; c.b_dtype = b_dtype; c.C = C; c.out_dtype = out_dtype;
+    c.s0 = row_scale; c.s1 = col_scale; c.scale_dtype = scale_dtype; c.col_scalar = col_scale_is_scalar != 0;
+    c.order = order != 0; c.epi = EPI_ROWCOL;
+    c.M = M; c.N = N; c.K = K; c.sam = sam; c.sak = sak; c.sbk = sbk; c.sbn = sbn;
+    return run_gemm("scaled_mm", c, (hipStream_t)stream);
+}
+
+extern "C" int gnk_tile_scaled_mm(const void *A, int a_dtype, const void *B, int b_dtype, void *C, int out_dtype,
+                                  const void *sA, const void *sB, int scale_dtype, int64_t M, int64_t N, int64_t K,
+                                  int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, int64_t ssam, int64_t ssak,
+                                  int64_t ssbk, int64_t ssbn, int64_t QM, int64_t QN, int64_t QK, void *stream) {
+    GemmCall c;
+    memset(&c, 0, sizeof(c));
+    c.A = A; c.a_dtype = a_dtype; c.B = B; c.b_dtype = b_dtype; c.C = C; c.out_dtype = out_dtype;
+    c.s0 = sA; c.s1 = sB; c.scale_dtype = scale_dtype; c.epi = EPI_TILE;
+    c.M = M; c.N = N; c.K = K; c.sam = sam; c.sak = sak; c.sbk = sbk; c.sbn = sbn;
+    c.ssam = ssam; c.ssak = ssak; c.ssbk = ssbk; c.ssbn = ssbn; c.QM = QM; c.QN = QN; c.QK = QK;
+    return run_gemm("tile_scaled_mm", c, (hipStream_t)stream);
+}
+
+extern "C" int gnk_fp8_mm(const void *A, int a_dtype, const void *B, int b_dtype, void *C, int out_dtype, int64_t M,
+                          int64_t N, int64_t K, int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, void *stream) {
+    if (!gnk_is_f8(a_dtype) || !gnk_is_f8(b_dtype)) return gnk_fail(GNK_ERR_BAD_ARG, "fp8_mm: operands must be fp8 (got dtype codes %d, %d)", a_dtype, b_dtype);
+    GemmCall c;
+    memset(&c, 0, sizeof(c));
+    c.A = A; c.a_dtype = a_dtype; c.B = B; c.b_dtype = b_dtype; c.C = C; c.out_dtype = out_dtype; c.epi = EPI_PLAIN;
+    c.M = M; c.N = N; c.K = K; c.sam = sam; c.sak = sak; c.sbk = sbk; c.sbn = sbn;
+    return run_gemm("fp8_mm", c, (hipStream_t)stream);
+}

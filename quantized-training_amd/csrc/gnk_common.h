@@ -1,0 +1,111 @@
+// gnk_common.h -- shared host/device helpers for libgnk_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/gnk.h"
+
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+
+#define GNK_LDS __attribute__((address_space(3)))
+#define GNK_GLOBAL __attribute__((address_space(1)))
+
+// ---------------------------------------------------------------- host-side error plumbing
+int gnk_fail(int code, const char *fmt, ...);   // records a thread-local message, returns code
+int gnk_check_launch(const char *what);        // hipGetLastError -> GNK_ERR_LAUNCH
+int gnk_num_cus(void);                         // CU count of the current device (cached)
+
+static inline bool gnk_is_float_dtype(int d) { return d == GNK_BF16 || d == GNK_F16 || d == GNK_F32; }
+static inline bool gnk_is_f8(int d) { return d == GNK_E4M3 || d == GNK_E5M2; }
+static inline int gnk_dtype_size(int d) {
+    switch (d) {
+    case GNK_BF16: case GNK_F16: return 2;
+    case GNK_F32: case GNK_I32: return 4;
+    default: return 1;
+    }
+}
+
+// ---------------------------------------------------------------- device numeric helpers
+// bf16 <-> f32 by bit manipulation: RNE, NaN stays NaN (matches torch's cast).
+__device__ __forceinline__ float gnk_bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+__device__ __forceinline__ unsigned short gnk_f32_to_bf16(float f) {
+    unsigned u = __float_as_uint(f);
+    unsigned r = u + 0x7fffu + ((u >> 16) & 1u);
+    r = ((u & 0x7fffffffu) > 0x7f800000u) ? (u | 0x00400000u) : r;
+    return (unsigned short)(r >> 16);
+}
+
+__device__ __forceinline__ float gnk_f16_to_f32(unsigned short h) {
+    _Float16 x;
+    __builtin_memcpy(&x, &h, 2);
+    return (float)x;
+}
+
+__device__ __forceinline__ unsigned short gnk_f32_to_f16(float f) {
+    _Float16 x = (_Float16)f;   // v_cvt_f16_f32: RNE
+    unsigned short h;
+    __builtin_memcpy(&h, &x, 2);
+    return h;
+}
+
+template <int DT> __device__ __forceinline__ float gnk_load_scalar(const void *p, int64_t i) {
+    if constexpr (DT == GNK_BF16) return gnk_bf16_to_f32(((const unsigned short *)p)[i]);
+    else if constexpr (DT == GNK_F16) return gnk_f16_to_f32(((const unsigned short *)p)[i]);
+    else return ((const float *)p)[i];
+}
+
+__device__ __forceinline__ float gnk_load_scalar_rt(const void *p, int dt, int64_t i) {
+    if (dt == GNK_BF16) return gnk_bf16_to_f32(((const unsigned short *)p)[i]);
+    if (dt == GNK_F16) return gnk_f16_to_f32(((const unsigned short *)p)[i]);
+    return ((const float *)p)[i];
+}
+
+__device__ __forceinline__ void gnk_store_scalar_rt(void *p, int dt, int64_t i, float v) {
+    if (dt == GNK_BF16) ((unsigned short *)p)[i] = gnk_f32_to_bf16(v);
+    else if (dt == GNK_F16) ((unsigned short *)p)[i] = gnk_f32_to_f16(v);
+    else ((float *)p)[i] = v;
+}
+
+// Philox4x32-10; the CPU oracle (oracle/gnk_oracle.c) carries the same generator so that the
+// stochastic-rounding kernels can be checked bit-for-bit.
+__device__ __forceinline__ void gnk_philox4x32_10(unsigned c[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
+        unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
+        unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0;
+        unsigned n1 = (unsigned)p1;
+        unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+        unsigned n3 = (unsigned)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// U[0,1) for logical element `idx` (24 random bits), one Philox block per element.
+__device__ __forceinline__ float gnk_sr_uniform(unsigned long long seed, unsigned long long offset,
+                                                unsigned long long idx) {
+    unsigned long long ctr = idx + offset;
+    unsigned c[4] = {(unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u};
+    gnk_philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+    return (float)(c[0] >> 8) * (1.0f / 16777216.0f);
+}
+
+// One quantization step of subclasses/int8.py:18-25 given the divisor max(scale, eps).
+template <bool SR>
+__device__ __forceinline__ int gnk_quant_one(float x, float div, unsigned long long seed,
+                                             unsigned long long offset, unsigned long long idx) {
+    float v = x / div;                     // true IEEE division (no fast-math in this build)
+    if constexpr (SR) v = floorf(v + gnk_sr_uniform(seed, offset, idx));
+    else v = rintf(v);                     // v_rndne_f32: round half to even
+    v = fminf(fmaxf(v, -128.0f), 127.0f);
+    return (int)v;
+}

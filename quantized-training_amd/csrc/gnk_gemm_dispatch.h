@@ -1,0 +1,59 @@
+// gnk_gemm_dispatch.h -- launcher table shared by the instantiation units and gnk_api.hip.
+#pragma once
+#include "gnk_gemm_kernel.h"
+
+// GEMM tile variants (gnk_set_gemm_variant):
+//   0: 256 x 256 tile, 8 waves (2 x 4), 128 KiB LDS, 1 workgroup / CU   -- large problems
+//   1: 128 x 128 tile, 4 waves (2 x 2),  64 KiB LDS, 2 workgroups / CU  -- mid-size problems
+//   2: generic 64 x 64 kernel (any strides / sizes; the fallback)
+enum { GNK_VARIANT_256 = 0, GNK_VARIANT_128 = 1, GNK_VARIANT_GENERIC = 2, GNK_NUM_FAST_VARIANTS = 2 };
+
+// fp8 format codes as the MFMA's cbsz/blgp fields want them
+enum { F8_E4M3 = 0, F8_E5M2 = 1 };
+
+// One launcher per (operand class, fp8 formats, tile variant): picks layout and epilogue at run time.
+typedef int (*gnk_gemm_launcher)(bool a_kmajor, bool b_kmajor, int epi, const GemmParams &p, hipStream_t st);
+
+#define GNK_DECLARE_LAUNCHER(NAME) int NAME(bool a_kmajor, bool b_kmajor, int epi, const GemmParams &p, hipStream_t st)
+
+GNK_DECLARE_LAUNCHER(gnk_launch_i8_v0);
+GNK_DECLARE_LAUNCHER(gnk_launch_i8_v1);
+GNK_DECLARE_LAUNCHER(gnk_launch_f8_00_v0);
+GNK_DECLARE_LAUNCHER(gnk_launch_f8_01_v0);
+GNK_DECLARE_LAUNCHER(gnk_launch_f8_10_v0);
+GNK_DECLARE_LAUNCHER(gnk_launch_f8_11_v0);
+GNK_DECLARE_LAUNCHER(gnk_launch_f8_00_v1);
+GNK_DECLARE_LAUNCHER(gnk_launch_f8_01_v1);
+GNK_DECLARE_LAUNCHER(gnk_launch_f8_10_v1);
+GNK_DECLARE_LAUNCHER(gnk_launch_f8_11_v1);
+
+// Defines NAME for the given tile shape / operand class: 4 layouts x 3 epilogues = 12 kernels.
+// The tile-scaled epilogue keeps a second (fp32) accumulator set, so it gets its own, smaller
+// wave tile (TBM x TBN over TWM x TWN waves).
+#define GNK_DEFINE_LAUNCHER(NAME, BM, BN, WM, WN, TBM, TBN, TWM, TWN, OP, FA, FB)                                               \
+    template <bool AK, bool BK> static int NAME##_l(int epi, const GemmParams &p, hipStream_t st) {         \
+        switch (epi) {                                                                                      \
+        case EPI_PLAIN: return gnk_gemm::launch<GemmCfg<BM, BN, WM, WN, AK, BK, OP, FA, FB, EPI_PLAIN>>(p, st);   \
+        case EPI_ROWCOL: return gnk_gemm::launch<GemmCfg<BM, BN, WM, WN, AK, BK, OP, FA, FB, EPI_ROWCOL>>(p, st); \
+        default: return gnk_gemm::launch<GemmCfg<TBM, TBN, TWM, TWN, AK, BK, OP, FA, FB, EPI_TILE>>(p, st);       \
+        }                                                                                                   \
+    }                                                                                                       \
+    int NAME(bool a_kmajor, bool b_kmajor, int epi, const GemmParams &p, hipStream_t st) {                  \
+        if (a_kmajor) return b_kmajor ? NAME##_l<true, true>(epi, p, st) : NAME##_l<true, false>(epi, p, st); \
+        return b_kmajor ? NAME##_l<false, true>(epi, p, st) : NAME##_l<false, false>(epi, p, st);           \
+    }
+
+// ---------------------------------------------------------------- generic fallback (gnk_gemm_generic.hip)
+struct GenericParams {
+    const char *A;
+    const char *B;
+    void *C;
+    const void *s0;
+    const void *s1;
+    int64_t M, N, K;
+    int64_t sam, sak, sbk, sbn;
+    int64_t ssam, ssak, ssbk, ssbn;
+    int64_t QM, QN, QK;
+    int epi, out_dtype, scale_dtype, col_scalar, order;
+};
+int gnk_launch_generic(int op, int fa, int fb, const GenericParams &p, hipStream_t st);

@@ -1,0 +1,405 @@
+// gnk_gemm_kernel.h -- LDS-staged MFMA GEMM for 8-bit operands on gfx950 (CDNA4).
+//
+//   C(M x N) = epilogue( A(M x K) @ B(K x N) ),   A, B: int8 or OCP fp8 (1 byte / element)
+//
+// One kernel template covers the reference's three GEMM families and all operand layouts:
+//   EPI_PLAIN : int32 (int8) or fp32->out (fp8) result      triton_mm.py:53-143, cutlass fp8_mm
+//   EPI_ROWCOL: (f32(acc) * row[m]) * col[n] -> bf16/f16/f32 triton_mm.py:146-220,382-407
+//   EPI_TILE  : per-128-K-block rescale, fp32 accumulate     triton_mm.py:223-342,410-441
+//
+// Design (MI355X-first, not a translation of the Triton kernels):
+//   * operands are staged global -> LDS with global_load_lds_dwordx4 (no VGPR round trip), two
+//     LDS buffers, the next K-step's loads in flight while the current one feeds the MFMAs;
+//   * a K-contiguous operand is kept as [rows][128 B] and read with ds_read_b128; an M/N-contiguous
+//     operand (the "column-major" layouts A@B and A.T@B of benchmark_mm.py:33-34) is kept exactly
+//     as it lies in memory, [128 k][rows], and transposed on the LDS->register hop with
+//     ds_read_b64_tr_b8, so global loads stay 16-byte coalesced and no transpose is materialised;
+//   * both images are XOR-swizzled (gnk_lds_layout.h) so fragment reads are bank-conflict free;
+//   * MFMA: v_mfma_i32_16x16x64_i8, or v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales
+//     (the only fp8 form that runs at 2x the bf16 rate on CDNA4);
+//   * the MFMA "A" operand is fed from matrix B and vice versa, so each lane ends up with 4
+//     consecutive n for one m: the epilogue packs them into one 8-byte (bf16) / 16-byte store;
+//   * workgroups are remapped so that the 8 XCDs (private L2s) each own a compact patch of tiles.
+#pragma once
+#include "gnk_common.h"
+#include "gnk_lds_layout.h"
+
+enum { EPI_PLAIN = 0, EPI_ROWCOL = 1, EPI_TILE = 2 };
+enum { OP_I8 = 0, OP_F8 = 1 };
+
+struct GemmParams {
+    const char *A;
+    const char *B;
+    void *C;
+    const void *s0;   // row scale (M) or tile scale A
+    const void *s1;   // col scale (N or 1) or tile scale B
+    int64_t M, N, K;
+    int64_t lda;      // elements between consecutive m (A K-major) or consecutive k (A M-major)
+    int64_t ldb;      // elements between consecutive n (B K-major) or consecutive k (B N-major)
+    int64_t ssam, ssak, ssbk, ssbn;   // tile-scale strides
+    int64_t QM, QN;                   // tile-scale block sizes along M and N (QK == 128)
+    int out_dtype, scale_dtype, col_scalar, order;
+    int grid_m, grid_n;
+};
+
+template <int BM_, int BN_, int WM_, int WN_, bool AK_, bool BK_, int OP_, int FA_, int FB_, int EPI_>
+struct GemmCfg {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+    static constexpr bool A_KMAJOR = AK_, B_KMAJOR = BK_;
+    static constexpr int OP = OP_, FA = FA_, FB = FB_, EPI = EPI_;
+    static constexpr int NW = WM * WN, NT = NW * 64;
+    static constexpr int WTM = BM / WM, WTN = BN / WN;    // wave tile
+    static constexpr int MT = WTM / 16, NTL = WTN / 16;   // 16x16 MFMA tiles per wave
+    static constexpr int A_BYTES = BM * GNK_BK, B_BYTES = BN * GNK_BK;
+    static constexpr int LDS_BYTES = 2 * (A_BYTES + B_BYTES);
+    static_assert(BM % (16 * WM) == 0 && BN % (16 * WN) == 0, "wave tile must be a multiple of 16");
+    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "1-KiB staging pieces must divide over the waves");
+};
+
+namespace gnk_gemm {
+
+// ------------------------------------------------------------------------------ tile mapping
+// XCD-aware: blocks b, b+8, b+16 ... share an XCD (observed round-robin placement; speed only).
+// Give every XCD a contiguous run of tile ids, then walk tiles in GROUP_M-tall column strips so
+// the run is a compact patch (e.g. 4 x 8 tiles at 4096^2 / 256^2 tiles).
+__device__ __forceinline__ void tile_of_block(int grid_m, int grid_n, int &tm, int &tn) {
+    const int nwg = grid_m * grid_n;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, idx = b >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective
+    constexpr int GROUP_M = 4;
+    const int width = GROUP_M * grid_n;
+    const int group = wg / width;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(grid_m - first_m, GROUP_M);
+    const int in = wg - group * width;
+    tm = first_m + in % gsz;
+    tn = in / gsz;
+}
+
+// ------------------------------------------------------------------------------ staging
+// Per-lane source pointers of this wave's 1-KiB pieces of one operand tile.
+template <bool KMAJOR, int ROWS, int NW>
+struct Stager {
+    static constexpr int NP = ROWS / 8 / NW;   // pieces per wave
+    const char *src[NP];
+    int64_t step;                              // bytes to advance per K-step
+
+    // base: operand pointer; ld: leading dimension; r0: first row (m0 / n0) of the tile;
+    // extent: M or N (rows are clamped so that every lane reads valid memory; clamped rows only
+    // feed output elements that the epilogue masks).
+    __device__ __forceinline__ void init(const char *base, int64_t ld, int64_t r0, int64_t extent, int wave, int lane) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int pc = i * NW + wave;
+            const int p = pc * 64 + lane;
+            if constexpr (KMAJOR) {
+                int r, c;
+                gnk_kmaj_stage_src(p, r, c);
+                int64_t row = r0 + r;
+                row = row < extent ? row : extent - 1;
+                src[i] = base + row * ld + 16 * c;
+            } else {
+                int k, c;
+                gnk_mnmaj_stage_src<ROWS>(p, k, c);
+                int64_t col = r0 + 16 * c;
+                col = col + 16 <= extent ? col : extent - 16;
+                src[i] = base + (int64_t)k * ld + col;
+            }
+        }
+        step = KMAJOR ? (int64_t)GNK_BK : (int64_t)GNK_BK * ld;
+    }
+
+    __device__ __forceinline__ void issue(char *tile, int wave) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int pc = i * NW + wave;
+            __builtin_amdgcn_global_load_lds((const GNK_GLOBAL void *)src[i], (GNK_LDS void *)(tile + pc * 1024), 16, 0, 0);
+            src[i] += step;
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------ fragment reads
+template <bool KMAJOR, int ROWS>
+__device__ __forceinline__ v4i load_frag(const char *tile, int rb, int ks, int lane) {
+    if constexpr (KMAJOR) {
+        return *(const GNK_LDS v4i *)(const GNK_LDS char *)(tile + gnk_kmaj_frag_offset(rb, ks, lane));
+    } else {
+        const int off = gnk_mnmaj_frag_offset<ROWS>(rb, ks, lane);
+        v2i lo = __builtin_amdgcn_ds_read_tr8_b64_v2i32((GNK_LDS v2i *)(tile + off));
+        v2i hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32((GNK_LDS v2i *)(tile + off + 8 * ROWS));
+        return (v4i){lo[0], lo[1], hi[0], hi[1]};
+    }
+}
+
+template <int OP> struct AccT;
+template <> struct AccT<OP_I8> { typedef v4i type; };
+template <> struct AccT<OP_F8> { typedef v4f type; };
+
+// one K-step (128 k) of MFMAs for this wave
+template <class Cfg>
+__device__ __forceinline__ void compute_step(const char *As, const char *Bs, typename AccT<Cfg::OP>::type (&acc)[Cfg::MT][Cfg::NTL],
+                                             int wm, int wn, int lane) {
+    constexpr int MT = Cfg::MT, NTL = Cfg::NTL;
+    if constexpr (Cfg::OP == OP_I8) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            v4i fa[MT], fb[NTL];
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) fb[j] = load_frag<Cfg::B_KMAJOR, Cfg::BN>(Bs, wn * Cfg::WTN + 16 * j, ks, lane);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[i] = load_frag<Cfg::A_KMAJOR, Cfg::BM>(As, wm * Cfg::WTM + 16 * i, ks, lane);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+    } else {
+        // fp8: one 16x16x128 MFMA per tile pair; lane slot (g, byte) <-> k = 64*(byte/16) + 16g + byte%16
+        // for BOTH operands (any consistent k permutation is a valid dot product).
+        v8i fb[NTL];
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            v4i lo = load_frag<Cfg::B_KMAJOR, Cfg::BN>(Bs, wn * Cfg::WTN + 16 * j, 0, lane);
+            v4i hi = load_frag<Cfg::B_KMAJOR, Cfg::BN>(Bs, wn * Cfg::WTN + 16 * j, 1, lane);
+            fb[j] = (v8i){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            v4i lo = load_frag<Cfg::A_KMAJOR, Cfg::BM>(As, wm * Cfg::WTM + 16 * i, 0, lane);
+            v4i hi = load_frag<Cfg::A_KMAJOR, Cfg::BM>(As, wm * Cfg::WTM + 16 * i, 1, lane);
+            v8i fa = (v8i){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+            for (int j = 0; j < NTL; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[j], fa, acc[i][j], Cfg::FB, Cfg::FA, 0, 0x7f7f7f7f, 0,
+                                                                             0x7f7f7f7f);   // E8M0 127 = 2^0
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ epilogue stores
+// OUT is a compile-time dtype and VEC says whether the 4 consecutive n of a lane can go out as one
+// 8/16-byte store (N % 4 == 0 and C 16-byte aligned); both are hoisted out of the tile loops so the
+// epilogue is straight-line code.
+template <int OUT, bool VEC>
+__device__ __forceinline__ void store4(void *C, int64_t m, int64_t n, int64_t M, int64_t N, float v0, float v1, float v2, float v3) {
+    if (m >= M || n >= N) return;
+    const int64_t idx = m * N + n;
+    if constexpr (VEC) {
+        if constexpr (OUT == GNK_BF16) {
+            v2i o = {(int)((unsigned)gnk_f32_to_bf16(v0) | ((unsigned)gnk_f32_to_bf16(v1) << 16)),
+                     (int)((unsigned)gnk_f32_to_bf16(v2) | ((unsigned)gnk_f32_to_bf16(v3) << 16))};
+            *(v2i *)((unsigned short *)C + idx) = o;
+        } else if constexpr (OUT == GNK_F16) {
+            v2i o = {(int)((unsigned)gnk_f32_to_f16(v0) | ((unsigned)gnk_f32_to_f16(v1) << 16)),
+                     (int)((unsigned)gnk_f32_to_f16(v2) | ((unsigned)gnk_f32_to_f16(v3) << 16))};
+            *(v2i *)((unsigned short *)C + idx) = o;
+        } else if constexpr (OUT == GNK_I32) {
+            *(v4i *)((int *)C + idx) = (v4i){__float_as_int(v0), __float_as_int(v1), __float_as_int(v2), __float_as_int(v3)};
+        } else {
+            *(v4f *)((float *)C + idx) = (v4f){v0, v1, v2, v3};
+        }
+    } else {
+        const float v[4] = {v0, v1, v2, v3};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + r < N) {
+                if constexpr (OUT == GNK_BF16) ((unsigned short *)C)[idx + r] = gnk_f32_to_bf16(v[r]);
+                else if constexpr (OUT == GNK_F16) ((unsigned short *)C)[idx + r] = gnk_f32_to_f16(v[r]);
+                else if constexpr (OUT == GNK_I32) ((int *)C)[idx + r] = __float_as_int(v[r]);
+                else ((float *)C)[idx + r] = v[r];
+            }
+    }
+}
+
+// Final values of one lane -> memory.  For OUT == GNK_I32 the floats carry int32 bit patterns.
+template <class Cfg, int OUT, bool VEC>
+__device__ __forceinline__ void epilogue(const GemmParams &p, typename AccT<Cfg::OP>::type (&acc)[Cfg::MT][Cfg::NTL],
+                                         v4f (*accf)[Cfg::EPI == EPI_TILE ? Cfg::NTL : 1], int64_t mrow, int64_t ncol) {
+    constexpr int MT = Cfg::MT, NTL = Cfg::NTL;
+    if constexpr (Cfg::EPI == EPI_PLAIN) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                if constexpr (Cfg::OP == OP_I8)
+                    store4<OUT, VEC>(p.C, mrow + 16 * i, ncol + 16 * j, p.M, p.N, __int_as_float(acc[i][j][0]), __int_as_float(acc[i][j][1]),
+                                     __int_as_float(acc[i][j][2]), __int_as_float(acc[i][j][3]));
+                else
+                    store4<OUT, VEC>(p.C, mrow + 16 * i, ncol + 16 * j, p.M, p.N, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+    } else if constexpr (Cfg::EPI == EPI_ROWCOL) {
+        float rs[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int64_t m = mrow + 16 * i;
+            rs[i] = m < p.M ? gnk_load_scalar_rt(p.s0, p.scale_dtype, m) : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            float cs[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t n = ncol + 16 * j + r;
+                cs[r] = p.col_scalar ? gnk_load_scalar_rt(p.s1, p.scale_dtype, 0)
+                                     : (n < p.N ? gnk_load_scalar_rt(p.s1, p.scale_dtype, n) : 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float a;
+                    if constexpr (Cfg::OP == OP_I8) a = (float)acc[i][j][r];   // v_cvt_f32_i32: RNE
+                    else a = acc[i][j][r];
+                    v[r] = p.order == 0 ? __fmul_rn(__fmul_rn(a, rs[i]), cs[r]) : __fmul_rn(__fmul_rn(a, cs[r]), rs[i]);
+                }
+                store4<OUT, VEC>(p.C, mrow + 16 * i, ncol + 16 * j, p.M, p.N, v[0], v[1], v[2], v[3]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j)
+                store4<OUT, VEC>(p.C, mrow + 16 * i, ncol + 16 * j, p.M, p.N, accf[i][j][0], accf[i][j][1], accf[i][j][2], accf[i][j][3]);
+    }
+}
+
+// ------------------------------------------------------------------------------ the kernel
+template <class Cfg>
+__global__ void __launch_bounds__(Cfg::NT) gemm_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MT = Cfg::MT, NTL = Cfg::NTL;
+    typedef typename AccT<Cfg::OP>::type acc_t;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+    int tm, tn;
+    tile_of_block(p.grid_m, p.grid_n, tm, tn);
+    const int64_t m0 = (int64_t)tm * Cfg::BM, n0 = (int64_t)tn * Cfg::BN;
+
+    // LDS carve: A buffers 0/1, then B buffers 0/1 (one dynamic array: see the guide's note on
+    // a second __shared__ object de-pipelining LDS-DMA loops)
+    char *const As0 = smem;
+    char *const Bs0 = smem + 2 * Cfg::A_BYTES;
+
+    Stager<Cfg::A_KMAJOR, Cfg::BM, Cfg::NW> sa;
+    Stager<Cfg::B_KMAJOR, Cfg::BN, Cfg::NW> sb;
+    sa.init(p.A, p.lda, m0, p.M, wave, lane);
+    sb.init(p.B, p.ldb, n0, p.N, wave, lane);
+
+    acc_t acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) acc[i][j] = (acc_t){0, 0, 0, 0};
+
+    // output coordinates of this lane: m = mrow + 16 i, n = ncol + 16 j + (0..3)
+    const int64_t mrow = m0 + wm * Cfg::WTM + (lane & 15);
+    const int64_t ncol = n0 + wn * Cfg::WTN + 4 * (lane >> 4);
+
+    // tile-scaled: fp32 running sum + per-K-block scales
+    v4f accf[Cfg::EPI == EPI_TILE ? MT : 1][Cfg::EPI == EPI_TILE ? NTL : 1];
+    if constexpr (Cfg::EPI == EPI_TILE) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) accf[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int nk = (int)(p.K / GNK_BK);
+    sa.issue(As0, wave);
+    sb.issue(Bs0, wave);
+    for (int t = 0; t < nk; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        // tile-scaled: fetch this K-block's scales BEFORE the next stage is issued, so that the
+        // wait on them cannot drain the LDS-DMA loads that should stay in flight under the MFMAs
+        float sav[Cfg::EPI == EPI_TILE ? MT : 1];
+        float sbv[Cfg::EPI == EPI_TILE ? NTL : 1][4];
+        if constexpr (Cfg::EPI == EPI_TILE) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                int64_t m = mrow + 16 * i;
+                m = m < p.M ? m : p.M - 1;
+                sav[i] = gnk_load_scalar_rt(p.s0, p.scale_dtype, (m / p.QM) * p.ssam + t * p.ssak);
+            }
+#pragma unroll
+            for (int j = 0; j < NTL; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int64_t n = ncol + 16 * j + r;
+                    n = n < p.N ? n : p.N - 1;
+                    sbv[j][r] = gnk_load_scalar_rt(p.s1, p.scale_dtype, t * p.ssbk + (n / p.QN) * p.ssbn);
+                }
+        }
+
+        const int cur = t & 1;
+        if (t + 1 < nk) {
+            sa.issue(As0 + (cur ^ 1) * Cfg::A_BYTES, wave);
+            sb.issue(Bs0 + (cur ^ 1) * Cfg::B_BYTES, wave);
+        }
+        compute_step<Cfg>(As0 + cur * Cfg::A_BYTES, Bs0 + cur * Cfg::B_BYTES, acc, wm, wn, lane);
+
+        if constexpr (Cfg::EPI == EPI_TILE) {
+            // acc_f32 += (f32(partial) * sA[m/QM, t]) * sB[t, n/QN]   (triton_mm.py:327-331), no FMA
+#pragma unroll
+            for (int j = 0; j < NTL; ++j)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float part;
+                        if constexpr (Cfg::OP == OP_I8) part = (float)acc[i][j][r];
+                        else part = acc[i][j][r];
+                        float tmp = __fmul_rn(part, sav[i]);
+                        tmp = __fmul_rn(tmp, sbv[j][r]);
+                        accf[i][j][r] = __fadd_rn(accf[i][j][r], tmp);
+                    }
+                    acc[i][j] = (acc_t){0, 0, 0, 0};
+                }
+        }
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    const bool vec_ok = (p.N % 4 == 0) && (((uintptr_t)p.C & 15) == 0);
+    if constexpr (Cfg::EPI == EPI_PLAIN && Cfg::OP == OP_I8) {
+        if (vec_ok) epilogue<Cfg, GNK_I32, true>(p, acc, accf, mrow, ncol);
+        else epilogue<Cfg, GNK_I32, false>(p, acc, accf, mrow, ncol);
+    } else {
+        if (p.out_dtype == GNK_BF16) {
+            if (vec_ok) epilogue<Cfg, GNK_BF16, true>(p, acc, accf, mrow, ncol);
+            else epilogue<Cfg, GNK_BF16, false>(p, acc, accf, mrow, ncol);
+        } else if (p.out_dtype == GNK_F16) {
+            if (vec_ok) epilogue<Cfg, GNK_F16, true>(p, acc, accf, mrow, ncol);
+            else epilogue<Cfg, GNK_F16, false>(p, acc, accf, mrow, ncol);
+        } else {
+            if (vec_ok) epilogue<Cfg, GNK_F32, true>(p, acc, accf, mrow, ncol);
+            else epilogue<Cfg, GNK_F32, false>(p, acc, accf, mrow, ncol);
+        }
+    }
+}
+
+template <class Cfg> int launch(const GemmParams &p0, hipStream_t st) {
+    GemmParams p = p0;
+    p.grid_m = (int)((p.M + Cfg::BM - 1) / Cfg::BM);
+    p.grid_n = (int)((p.N + Cfg::BN - 1) / Cfg::BN);
+    static bool attr_set[64] = {};   // opt in to > 64 KiB of dynamic LDS once per device and kernel instance
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return gnk_fail(GNK_ERR_LAUNCH, "gemm: no current HIP device");
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute((const void *)gemm_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess)
+            return gnk_fail(GNK_ERR_LAUNCH, "gemm: cannot reserve %d bytes of LDS", Cfg::LDS_BYTES);
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<Cfg>), dim3((unsigned)(p.grid_m * p.grid_n)), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p);
+    return gnk_check_launch("gemm");
+}
+
+}  // namespace gnk_gemm

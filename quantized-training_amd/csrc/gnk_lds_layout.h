@@ -1,0 +1,61 @@
+// gnk_lds_layout.h -- LDS image index math of the MFMA GEMM, usable from host and device so that
+// tests/test_lds_layout.py can simulate stage -> read round trips (including the
+// ds_read_b64_tr_b8 gather) on the CPU.
+//
+// A K-step tile of either operand is ROWS x 128 bytes (int8 / fp8: one byte per element).
+//
+//  * K-major tile  (the operand's K dim is contiguous in memory):  image [ROWS][128 B].
+//    16-byte chunk c (k = 16c .. 16c+15) of row r is stored in slot  c ^ ((r >> 1) & 7).
+//    MFMA fragments are read with ds_read_b128; the XOR makes every 16-lane group of a
+//    16x16x64 / 32x32x32 fragment read hit 16 distinct 16-B bank slots.
+//
+//  * MN-major tile (the operand's M or N dim is contiguous):       image [128 k][L B], L = ROWS.
+//    16-byte chunk c (n = 16c .. 16c+15) of k-row k is stored in slot c ^ swz(k);
+//    fragments are gathered with ds_read_b64_tr_b8 (8 k-rows x 16 columns per 16 lanes).
+//
+// global_load_lds writes LDS linearly (wave-uniform base + lane * 16), so the swizzle is applied
+// to the per-lane SOURCE address when staging and to the address when reading.
+#pragma once
+
+#if defined(__HIPCC__)
+#define GNK_HD __host__ __device__ __forceinline__
+#else
+#define GNK_HD inline
+#endif
+
+constexpr int GNK_BK = 128;   // bytes (= elements) of K per staged tile
+
+GNK_HD int gnk_kmaj_offset(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+template <int L> GNK_HD int gnk_mnmaj_swz(int k) {
+    static_assert(L == 128 || L == 256, "MN-major tiles are 128 or 256 bytes wide");
+    if (L == 256) return ((k & 7) << 1) | ((k >> 4) & 1);
+    return (((k >> 1) & 3) << 1) | ((k >> 4) & 1);
+}
+template <int L> GNK_HD int gnk_mnmaj_offset(int k, int c) { return k * L + ((c ^ gnk_mnmaj_swz<L>(k)) << 4); }
+
+// ---- staging: which (row, chunk) of the tile does LDS 16-byte position p hold? -------------
+// K-major:  p = r * 8 + slot
+GNK_HD void gnk_kmaj_stage_src(int p, int &r, int &c) {
+    r = p >> 3;
+    c = (p & 7) ^ ((r >> 1) & 7);
+}
+// MN-major: p = k * (L/16) + slot
+template <int L> GNK_HD void gnk_mnmaj_stage_src(int p, int &k, int &c) {
+    k = p / (L / 16);
+    c = (p % (L / 16)) ^ gnk_mnmaj_swz<L>(k);
+}
+
+// ---- fragment reads for one 16-row (or 16-column) x 64-k MFMA operand ------------------------
+// lane l supplies fragment row (l & 15) and k-slot group g = l >> 4; its 16 bytes are
+// k = 64*ks + 16*g + (0..15).
+// K-major: one ds_read_b128 at this offset (rb = first row of the 16-row fragment in the tile).
+GNK_HD int gnk_kmaj_frag_offset(int rb, int ks, int lane) {
+    return gnk_kmaj_offset(rb + (lane & 15), 4 * ks + (lane >> 4));
+}
+// MN-major: two ds_read_b64_tr_b8; the first at this offset (k rows 64ks+16g .. +7), the second
+// 8*L further (k rows +8 .. +15).  rb = first column of the fragment in the tile (multiple of 16).
+template <int L> GNK_HD int gnk_mnmaj_frag_offset(int rb, int ks, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 1, hb = lane & 1;
+    return gnk_mnmaj_offset<L>(64 * ks + 16 * g + q, rb >> 4) + 8 * hb;
+}

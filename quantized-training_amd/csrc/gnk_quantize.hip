@@ -1,0 +1,348 @@
+// gnk_quantize.hip -- absmax symmetric INT8 quantization for gfx950 (HBM-bound).
+//
+// Restates subclasses/int8.py:12-26 of the reference as hand-written kernels:
+//   * rowwise  : reduction along the contiguous dim. One wave per row; the row is read ONCE with
+//                16-byte loads and kept in registers between the absmax and the quantize step
+//                (algorithmic traffic 3 B/elem for bf16 -> int8).
+//   * colwise  : reduction along the strided dim (the grad-input / grad-weight operands of
+//                subclasses/mixed_precision.py:178,186).  Pass 1: per-column absmax into an fp32
+//                workspace with one atomicMax per block and column; pass 2: quantize in place of
+//                the reference's strided reduction + transpose copy. Output keeps x's layout, so
+//                the GEMM consumes it through its transposed-operand (ds_read_b64_tr_b8) path.
+//   * generic  : any strides / alignment / dtype, one block per logical row (slow, correct).
+#include "gnk_common.h"
+
+namespace {
+
+template <int DT> struct ElemTraits;
+template <> struct ElemTraits<GNK_BF16> { static constexpr int VEC = 8; };
+template <> struct ElemTraits<GNK_F16>  { static constexpr int VEC = 8; };
+template <> struct ElemTraits<GNK_F32>  { static constexpr int VEC = 4; };
+
+// unpack one 16-byte chunk into VEC floats
+template <int DT> __device__ __forceinline__ void unpack16(const v4i &raw, float *out) {
+    if constexpr (DT == GNK_F32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[i] = __int_as_float(raw[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned w = (unsigned)raw[i];
+            if constexpr (DT == GNK_BF16) {
+                out[2 * i] = __uint_as_float(w << 16);
+                out[2 * i + 1] = __uint_as_float(w & 0xffff0000u);
+            } else {
+                out[2 * i] = gnk_f16_to_f32((unsigned short)(w & 0xffffu));
+                out[2 * i + 1] = gnk_f16_to_f32((unsigned short)(w >> 16));
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__device__ __forceinline__ unsigned pack4_i8(int a, int b, int c, int d) {
+    return (unsigned)(a & 0xff) | ((unsigned)(b & 0xff) << 8) | ((unsigned)(c & 0xff) << 16) | ((unsigned)(d & 0xff) << 24);
+}
+
+// ------------------------------------------------------------------------------------------
+// rowwise: one wave per row, NCH 16-byte chunks per lane held in registers.
+// Requirements (checked on the host): sxc == 1, sqc == 1, C % VEC == 0, row starts 16-B aligned
+// for x and VEC-byte aligned for q, C <= 64 * VEC * NCH.
+// ------------------------------------------------------------------------------------------
+template <int DT, int NCH, bool SR>
+__global__ void __launch_bounds__(256)
+quant_rowwise_kernel(const char *__restrict__ x, int8_t *__restrict__ q, void *__restrict__ scale,
+                     int64_t R, int64_t C, int64_t sxr_bytes, int64_t sqr, float eps,
+                     unsigned long long seed, unsigned long long offset) {
+    constexpr int VEC = ElemTraits<DT>::VEC;
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;                                      // wave-uniform
+    const int nchunks = (int)(C / VEC);
+    const char *xrow = x + r * sxr_bytes;
+
+    v4i raw[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = i * 64 + lane;
+        raw[i] = (v4i){0, 0, 0, 0};
+        if (ch < nchunks) raw[i] = *(const v4i *)(xrow + (int64_t)ch * 16);
+    }
+    float amax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        float f[VEC];
+        unpack16<DT>(raw[i], f);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) amax = fmaxf(amax, fabsf(f[j]));
+    }
+    amax = wave_max(amax);
+    const float s = amax / 127.0f;
+    const float div = fmaxf(s, eps);
+    if (lane == 0) gnk_store_scalar_rt(scale, DT, r, s);
+
+    int8_t *qrow = q + r * sqr;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = i * 64 + lane;
+        if (ch < nchunks) {
+            float f[VEC];
+            unpack16<DT>(raw[i], f);
+            int qi[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                qi[j] = gnk_quant_one<SR>(f[j], div, seed, offset, (unsigned long long)(r * C + (int64_t)ch * VEC + j));
+            if constexpr (VEC == 8) {
+                v2i o = {(int)pack4_i8(qi[0], qi[1], qi[2], qi[3]), (int)pack4_i8(qi[4], qi[5], qi[6], qi[7])};
+                *(v2i *)(qrow + (int64_t)ch * 8) = o;
+            } else {
+                *(unsigned *)(qrow + (int64_t)ch * 4) = pack4_i8(qi[0], qi[1], qi[2], qi[3]);
+            }
+        }
+    }
+}
+
+// rowwise for very long rows: one block (256 threads) per row, two passes (second pass re-reads
+// the row, which is L2-resident).
+template <int DT, bool SR>
+__global__ void __launch_bounds__(256)
+quant_rowwise_long_kernel(const char *__restrict__ x, int8_t *__restrict__ q, void *__restrict__ scale,
+                          int64_t R, int64_t C, int64_t sxr_bytes, int64_t sqr, float eps,
+                          unsigned long long seed, unsigned long long offset) {
+    constexpr int VEC = ElemTraits<DT>::VEC;
+    __shared__ float red[4];
+    const int64_t r = blockIdx.x;
+    const int64_t nchunks = C / VEC;
+    const char *xrow = x + r * sxr_bytes;
+    float amax = 0.0f;
+    for (int64_t ch = threadIdx.x; ch < nchunks; ch += 256) {
+        float f[VEC];
+        unpack16<DT>(*(const v4i *)(xrow + ch * 16), f);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) amax = fmaxf(amax, fabsf(f[j]));
+    }
+    amax = wave_max(amax);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float s = amax / 127.0f;
+    const float div = fmaxf(s, eps);
+    if (threadIdx.x == 0) gnk_store_scalar_rt(scale, DT, r, s);
+    int8_t *qrow = q + r * sqr;
+    for (int64_t ch = threadIdx.x; ch < nchunks; ch += 256) {
+        float f[VEC];
+        unpack16<DT>(*(const v4i *)(xrow + ch * 16), f);
+        int qi[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+            qi[j] = gnk_quant_one<SR>(f[j], div, seed, offset, (unsigned long long)(r * C + ch * VEC + j));
+        if constexpr (VEC == 8) {
+            v2i o = {(int)pack4_i8(qi[0], qi[1], qi[2], qi[3]), (int)pack4_i8(qi[4], qi[5], qi[6], qi[7])};
+            *(v2i *)(qrow + ch * 8) = o;
+        } else {
+            *(unsigned *)(qrow + ch * 4) = pack4_i8(qi[0], qi[1], qi[2], qi[3]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// colwise: memory matrix [P][Q] (Q contiguous); logical rows are the Q columns, the reduction
+// runs over P.  Block = 32 column-lanes (VEC columns each) x 8 row-lanes over a PB-row slab.
+// ------------------------------------------------------------------------------------------
+constexpr int COL_PB = 128;   // rows per block
+
+template <int DT>
+__global__ void __launch_bounds__(256)
+col_absmax_kernel(const char *__restrict__ x, unsigned *__restrict__ amax_ws, int64_t P, int64_t Q,
+                  int64_t ld_bytes) {
+    constexpr int VEC = ElemTraits<DT>::VEC;
+    __shared__ float red[8][32 * VEC + 1];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int64_t col0 = ((int64_t)blockIdx.x * 32 + cl) * VEC;
+    const int64_t row0 = (int64_t)blockIdx.y * COL_PB;
+    float m[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) m[j] = 0.0f;
+    if (col0 < Q) {
+#pragma unroll 4
+        for (int i = 0; i < COL_PB / 8; ++i) {
+            const int64_t row = row0 + i * 8 + rl;
+            if (row < P) {
+                float f[VEC];
+                unpack16<DT>(*(const v4i *)(x + row * ld_bytes + col0 * (16 / VEC)), f);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) m[j] = fmaxf(m[j], fabsf(f[j]));
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) red[rl][cl * VEC + j] = m[j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < 32 * VEC; c += 256) {
+        float v = red[0][c];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) v = fmaxf(v, red[i][c]);
+        const int64_t col = (int64_t)blockIdx.x * 32 * VEC + c;
+        // non-negative floats order like their bit patterns
+        if (col < Q && v > 0.0f) atomicMax(amax_ws + col, __float_as_uint(v));
+    }
+}
+
+template <int DT, bool SR>
+__global__ void __launch_bounds__(256)
+col_quant_kernel(const char *__restrict__ x, int8_t *__restrict__ q, void *__restrict__ scale,
+                 const unsigned *__restrict__ amax_ws, int64_t P, int64_t Q, int64_t ld_bytes,
+                 int64_t ldq, float eps, unsigned long long seed, unsigned long long offset) {
+    constexpr int VEC = ElemTraits<DT>::VEC;
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int64_t col0 = ((int64_t)blockIdx.x * 32 + cl) * VEC;
+    const int64_t row0 = (int64_t)blockIdx.y * COL_PB;
+    if (col0 >= Q) return;
+    float div[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const float s = __uint_as_float(amax_ws[col0 + j]) / 127.0f;
+        div[j] = fmaxf(s, eps);
+        if (blockIdx.y == 0 && rl == 0) gnk_store_scalar_rt(scale, DT, col0 + j, s);
+    }
+#pragma unroll 4
+    for (int i = 0; i < COL_PB / 8; ++i) {
+        const int64_t row = row0 + i * 8 + rl;
+        if (row < P) {
+            float f[VEC];
+            unpack16<DT>(*(const v4i *)(x + row * ld_bytes + col0 * (16 / VEC)), f);
+            int qi[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)   // logical element (r = col, c = row) of the (Q, P) view
+                qi[j] = gnk_quant_one<SR>(f[j], div[j], seed, offset, (unsigned long long)((col0 + j) * P + row));
+            if constexpr (VEC == 8) {
+                v2i o = {(int)pack4_i8(qi[0], qi[1], qi[2], qi[3]), (int)pack4_i8(qi[4], qi[5], qi[6], qi[7])};
+                *(v2i *)(q + row * ldq + col0) = o;
+            } else {
+                *(unsigned *)(q + row * ldq + col0) = pack4_i8(qi[0], qi[1], qi[2], qi[3]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// generic: any strides, one block per logical row, two strided passes.
+// ------------------------------------------------------------------------------------------
+template <bool SR>
+__global__ void __launch_bounds__(256)
+quant_generic_kernel(const void *__restrict__ x, int dt, int8_t *__restrict__ q, void *__restrict__ scale,
+                     int64_t R, int64_t C, int64_t sxr, int64_t sxc, int64_t sqr, int64_t sqc, float eps,
+                     unsigned long long seed, unsigned long long offset) {
+    __shared__ float red[4];
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        float amax = 0.0f;
+        for (int64_t c = threadIdx.x; c < C; c += 256) amax = fmaxf(amax, fabsf(gnk_load_scalar_rt(x, dt, r * sxr + c * sxc)));
+        amax = wave_max(amax);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+        __syncthreads();
+        amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const float s = amax / 127.0f;
+        const float div = fmaxf(s, eps);
+        if (threadIdx.x == 0) gnk_store_scalar_rt(scale, dt, r, s);
+        for (int64_t c = threadIdx.x; c < C; c += 256)
+            q[r * sqr + c * sqc] = (int8_t)gnk_quant_one<SR>(gnk_load_scalar_rt(x, dt, r * sxr + c * sxc), div, seed, offset,
+                                                             (unsigned long long)(r * C + c));
+    }
+}
+
+template <int DT, bool SR>
+int launch_rowwise(const void *x, int8_t *q, void *scale, int64_t R, int64_t C, int64_t sxr, int64_t sqr, float eps,
+                   uint64_t seed, uint64_t offset, hipStream_t st) {
+    constexpr int VEC = ElemTraits<DT>::VEC;
+    const int64_t sxr_bytes = sxr * (16 / VEC);
+    const int64_t per_lane = (C / VEC + 63) / 64;
+    const dim3 grid((unsigned)((R + 3) / 4)), block(256);
+#define GNK_ROW(NCH)                                                                                              \
+    hipLaunchKernelGGL((quant_rowwise_kernel<DT, NCH, SR>), grid, block, 0, st, (const char *)x, q, scale, R, C,  \
+                       sxr_bytes, sqr, eps, seed, offset)
+    if (per_lane <= 1) GNK_ROW(1);
+    else if (per_lane <= 2) GNK_ROW(2);
+    else if (per_lane <= 4) GNK_ROW(4);
+    else if (per_lane <= 8) GNK_ROW(8);
+    else if (per_lane <= 16) GNK_ROW(16);
+    else
+        hipLaunchKernelGGL((quant_rowwise_long_kernel<DT, SR>), dim3((unsigned)R), block, 0, st, (const char *)x, q, scale,
+                           R, C, sxr_bytes, sqr, eps, seed, offset);
+#undef GNK_ROW
+    return gnk_check_launch("quantize_int8 rowwise");
+}
+
+template <int DT, bool SR>
+int launch_colwise(const void *x, int8_t *q, void *scale, int64_t P, int64_t Q, int64_t ld, int64_t ldq, float eps,
+                   uint64_t seed, uint64_t offset, unsigned *ws, hipStream_t st) {
+    constexpr int VEC = ElemTraits<DT>::VEC;
+    const int64_t ld_bytes = ld * (16 / VEC);
+    if (hipMemsetAsync(ws, 0, (size_t)Q * 4, st) != hipSuccess) return gnk_fail(GNK_ERR_LAUNCH, "quantize_int8: memset of workspace failed");
+    const dim3 grid((unsigned)((Q + 32 * VEC - 1) / (32 * VEC)), (unsigned)((P + COL_PB - 1) / COL_PB)), block(256);
+    hipLaunchKernelGGL((col_absmax_kernel<DT>), grid, block, 0, st, (const char *)x, ws, P, Q, ld_bytes);
+    hipLaunchKernelGGL((col_quant_kernel<DT, SR>), grid, block, 0, st, (const char *)x, q, scale, ws, P, Q, ld_bytes, ldq,
+                       eps, seed, offset);
+    return gnk_check_launch("quantize_int8 colwise");
+}
+
+inline bool aligned(const void *p, int a) { return ((uintptr_t)p % a) == 0; }
+
+}  // namespace
+
+extern "C" int64_t gnk_quantize_int8_workspace_bytes(int64_t R, int64_t C, int64_t sxr, int64_t sxc) {
+    (void)C;
+    if (sxc == 1 || R <= 0) return 0;
+    return sxr == 1 ? R * 4 : 0;
+}
+
+extern "C" int gnk_quantize_int8(const void *x, int x_dtype, int64_t R, int64_t C, int64_t sxr, int64_t sxc,
+                                 int8_t *q, int64_t sqr, int64_t sqc, void *scale, float eps, int sr, uint64_t seed,
+                                 uint64_t offset, void *workspace, int64_t workspace_bytes, void *stream) {
+    if (R < 0 || C < 0) return gnk_fail(GNK_ERR_BAD_ARG, "quantize_int8: negative size (%lld, %lld)", (long long)R, (long long)C);
+    if (!gnk_is_float_dtype(x_dtype)) return gnk_fail(GNK_ERR_BAD_ARG, "quantize_int8: input dtype code %d is not bf16/f16/f32", x_dtype);
+    if (R == 0) return GNK_OK;
+    if (!scale) return gnk_fail(GNK_ERR_BAD_ARG, "quantize_int8: null scale pointer");
+    if (C > 0 && (!x || !q)) return gnk_fail(GNK_ERR_BAD_ARG, "quantize_int8: null data pointer");
+    int rc = gnk_init();
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int esz = gnk_dtype_size(x_dtype);
+    const int vec = 16 / esz;
+
+#define GNK_DISPATCH(FN, ...)                                                         \
+    do {                                                                              \
+        if (x_dtype == GNK_BF16) return sr ? FN<GNK_BF16, true>(__VA_ARGS__) : FN<GNK_BF16, false>(__VA_ARGS__); \
+        if (x_dtype == GNK_F16) return sr ? FN<GNK_F16, true>(__VA_ARGS__) : FN<GNK_F16, false>(__VA_ARGS__);    \
+        return sr ? FN<GNK_F32, true>(__VA_ARGS__) : FN<GNK_F32, false>(__VA_ARGS__); \
+    } while (0)
+
+    // reduction along the contiguous dim
+    if (C > 0 && sxc == 1 && sqc == 1 && C % vec == 0 && aligned(x, 16) && (sxr * esz) % 16 == 0 && aligned(q, vec) &&
+        sqr % vec == 0 && sxr >= C && sqr >= C) {
+        GNK_DISPATCH(launch_rowwise, x, q, scale, R, C, sxr, sqr, eps, seed, offset, st);
+    }
+    // reduction along the strided dim: memory is [P = C][Q = R] with Q contiguous
+    if (C > 0 && sxr == 1 && sqr == 1 && R % vec == 0 && aligned(x, 16) && (sxc * esz) % 16 == 0 && aligned(q, vec) &&
+        sqc % vec == 0 && sxc >= R && sqc >= R) {
+        if (!workspace || workspace_bytes < R * 4)
+            return gnk_fail(GNK_ERR_WORKSPACE, "quantize_int8: strided reduction needs a workspace of %lld bytes", (long long)(R * 4));
+        GNK_DISPATCH(launch_colwise, x, q, scale, /*P=*/C, /*Q=*/R, /*ld=*/sxc, /*ldq=*/sqc, eps, seed, offset,
+                     (unsigned *)workspace, st);
+    }
+#undef GNK_DISPATCH
+    // anything else (C == 0 included: scale = 0, nothing to write)
+    const unsigned grid = (unsigned)(R < 4096 ? R : 4096);
+    if (sr)
+        hipLaunchKernelGGL((quant_generic_kernel<true>), dim3(grid), dim3(256), 0, st, x, x_dtype, q, scale, R, C, sxr, sxc,
+                           sqr, sqc, eps, seed, offset);
+    else
+        hipLaunchKernelGGL((quant_generic_kernel<false>), dim3(grid), dim3(256), 0, st, x, x_dtype, q, scale, R, C, sxr, sxc,
+                           sqr, sqc, eps, seed, offset);
+    return gnk_check_launch("quantize_int8 generic");
+}

@@ -1,0 +1,88 @@
+"""ctypes binding of libgnk_hip.so (include/gnk.h) -- the only bridge between Python and the
+hand-written gfx950 kernels.  There is no CPU or eager fallback here: if the library is missing,
+or a call fails, the op raises."""
+from __future__ import annotations
+
+import ctypes
+from pathlib import Path
+
+import torch
+
+_LIB_PATH = Path(__file__).resolve().parent / "libgnk_hip.so"
+ABI_VERSION = 1
+
+BF16, F16, F32, I8, E4M3, E5M2, I32 = range(7)
+DTYPE_CODE = {
+    torch.bfloat16: BF16,
+    torch.float16: F16,
+    torch.float32: F32,
+    torch.int8: I8,
+    torch.float8_e4m3fn: E4M3,
+    torch.float8_e5m2: E5M2,
+    torch.int32: I32,
+}
+
+_lib = None
+
+
+def library_path() -> Path:
+    return _LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """Load libgnk_hip.so once; fail loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise RuntimeError(
+            f"{_LIB_PATH} is missing: build it with `make -C quantized-training_amd/csrc -j8` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). gn_kernels has no fallback path."
+        )
+    L = ctypes.CDLL(str(_LIB_PATH))
+    i64, vp, ci, u64, f32 = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_float
+    L.gnk_abi_version.restype = ci
+    L.gnk_last_error.restype = ctypes.c_char_p
+    L.gnk_init.restype = ci
+    L.gnk_set_gemm_variant.argtypes = [ci]
+    L.gnk_quantize_int8.argtypes = [vp, ci, i64, i64, i64, i64, vp, i64, i64, vp, f32, ci, u64, u64, vp, i64, vp]
+    L.gnk_quantize_int8_workspace_bytes.argtypes = [i64, i64, i64, i64]
+    L.gnk_quantize_int8_workspace_bytes.restype = i64
+    L.gnk_int8_mm.argtypes = [vp, vp, vp] + [i64] * 7 + [vp]
+    L.gnk_scaled_mm.argtypes = [vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci] + [i64] * 7 + [vp]
+    L.gnk_tile_scaled_mm.argtypes = [vp, ci, vp, ci, vp, ci, vp, vp, ci] + [i64] * 14 + [vp]
+    L.gnk_fp8_mm.argtypes = [vp, ci, vp, ci, vp, ci] + [i64] * 7 + [vp]
+    if L.gnk_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libgnk_hip.so ABI {L.gnk_abi_version()} != expected {ABI_VERSION}; rebuild it")
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().gnk_last_error().decode(errors="replace")
+        raise RuntimeError(f"gn_kernels::{what} failed (status {rc}): {msg}")
+
+
+def stream_of(t: torch.Tensor) -> int:
+    """hipStream_t of the calling thread's current stream on t's device."""
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class device_of:
+    """Make t's device current for the duration of a launch (no-op when it already is)."""
+
+    def __init__(self, t: torch.Tensor):
+        self.idx = t.device.index
+        self.prev = None
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if self.idx is not None and self.idx != cur:
+            self.prev = cur
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+        return False
