@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X scaled low-precision matmul path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload (BASELINE.json configs[1], the configuration the TOPS metric is quoted on; inputs follow
+the reference's benchmark_mm.py:60,78-96,125-126): one STEP = the six scaled GEMMs at M=N=K=4096 --
+scaled INT8 and scaled FP8 (e4m3), each in the three operand layouts A@B.T, A@B and A.T@B -- through
+`gn_kernels.scaled_mm` (op -> C ABI -> hand-written gfx950 kernels), bf16 scales and bf16 output.
+Operands are resident in HBM before the timed region.  `value` is the whole-job rate
+(2*M*N*K ops per GEMM, the reference's convention benchmark_mm.py:107) over all ranks.
+
+With --gpus N > 1 (launched by torch.distributed.run) every rank runs the same step on its own GPU
+("replicas only": a single GEMM is not split across GPUs) -> weak scaling.
+
+Extra objects on the JSON line:
+  roofline     -- the dominant kernel (scaled INT8 A@B.T), timed live with HIP events on the launch stream
+  cpu_baseline -- the reference's CPU fallback formula (torch._int_mm + dequant scale) on the host cores
+  detail       -- per-kernel TOPS of the sweep 1024/2048/4096 and quantize-pass GB/s (outside the timed region)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path[:0] = [str(ROOT / "quantized-training_amd"), str(ROOT)]
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_DENSE_8BIT_TOPS = 5033.0      # 256 CU x 4 SIMD x 2048 op/clk x 2.4 GHz (MI355X_MICROARCH.md: i8 and MX-fp8 = 2x bf16)
+PEAK_HBM_GBS = 8000.0
+
+
+def to_layout(x, column_major):
+    return x.T.contiguous().T if column_major else x.contiguous()
+
+
+LAYOUTS = {"A@B.T": (False, True), "A@B": (False, False), "A.T@B": (True, False)}
+
+
+def make_inputs(S, dev):
+    """benchmark_mm.py:82-86,125-126"""
+    A_i8 = torch.randint(-128, 127, (S, S), dtype=torch.int8, device=dev)
+    B_i8 = torch.randint(-128, 127, (S, S), dtype=torch.int8, device=dev)
+    A_f8 = torch.randn(S, S, device=dev).to(torch.float8_e4m3fn)
+    B_f8 = torch.randn(S, S, device=dev).to(torch.float8_e4m3fn)
+    sA = torch.randn(S, 1, device=dev).div(128).bfloat16()
+    sB = torch.randn(1, S, device=dev).div(128).bfloat16()
+    tsA = torch.randn(S, S // 128, device=dev).div(128).bfloat16()
+    tsB = torch.randn(S // 128, S // 128, device=dev).div(128).bfloat16()
+    cases = {}
+    for name, (acm, bcm) in LAYOUTS.items():
+        cases[("int8", name)] = (to_layout(A_i8, acm), to_layout(B_i8, bcm), sA, sB)
+        cases[("fp8", name)] = (to_layout(A_f8, acm), to_layout(B_f8, bcm), sA, sB)
+        cases[("tile_int8", name)] = (to_layout(A_i8, acm), to_layout(B_i8, bcm), to_layout(tsA, acm), to_layout(tsB, bcm))
+        cases[("tile_fp8", name)] = (to_layout(A_f8, acm), to_layout(B_f8, bcm), to_layout(tsA, acm), to_layout(tsB, bcm))
+    return cases
+
+
+def time_kernel(fn, iters=30, warm=5):
+    """Average launch duration in ms, HIP events on the current (= launch) stream."""
+    for _ in range(warm):
+        fn()
+    start = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+    stop = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+    for i in range(iters):
+        start[i].record()
+        fn()
+        stop[i].record()
+    torch.cuda.synchronize()
+    ts = sorted(s.elapsed_time(e) for s, e in zip(start, stop))
+    return sum(ts) / len(ts), ts[len(ts) // 2]
+
+
+def cpu_baseline(S=4096, budget_s=12.0):
+    """The reference's CPU path (benchmark_mm.py:41, uncompiled): torch._int_mm + fp32 scale + cast, on
+    the same 4096^3 A@B.T problem.  Imported from oracle/ -- the checker, timed as a baseline only."""
+    from oracle import torch_ref
+
+    torch.manual_seed(2025 * 2024)
+    A = torch.randint(-128, 127, (S, S), dtype=torch.int8)
+    B = torch.randint(-128, 127, (S, S), dtype=torch.int8).T.contiguous().T
+    sA = torch.randn(S, 1).div(128).bfloat16()
+    sB = torch.randn(1, S).div(128).bfloat16()
+    torch_ref.scaled_mm_intmm(A, B, sA, sB)
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while time.perf_counter() < t_end and len(times) < 20:
+        t0 = time.perf_counter()
+        torch_ref.scaled_mm_intmm(A, B, sA, sB)
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(2 * S ** 3 / med * 1e-12, 4), "unit": "TOPS", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"scaled INT8 A@B.T {S}^3 via torch._int_mm + fp32 scale -> bf16 (reference fallback formula), "
+                      f"median of {len(times)} runs, {med * 1e3:.1f} ms each"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-detail", action="store_true", help="skip the untimed per-kernel sweep")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import gn_kernels
+    from gn_kernels import _cabi
+
+    _cabi.load().gnk_init()
+    torch.manual_seed(2025 * 2024 + rank)
+    S = 4096
+    cases = make_inputs(S, dev)
+    step_keys = [(d, l) for d in ("int8", "fp8") for l in LAYOUTS]
+
+    def step():
+        for k in step_keys:
+            gn_kernels.scaled_mm(*cases[k])
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    ops_per_step = len(step_keys) * 2 * S ** 3
+    value = world * ops_per_step * args.steps / elapsed * 1e-12
+
+    out = {
+        "metric": "scaled INT8/FP8 mm TOPS @4096 (A@B.T, A@B, A.T@B)",
+        "value": round(value, 2),
+        "unit": "TOPS",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int8+fp8_e4m3 (int32 / fp32 accumulate, bf16 out)",
+        "data": "synthetic",
+        "config": {"workload": "configs[1]: scaled INT8 + scaled FP8 mm, M=N=K=4096, layouts A@B.T / A@B / A.T@B, 6 GEMMs per step",
+                   "parallelism": f"replicas x{world}" if world > 1 else "single GPU"},
+    }
+
+    if rank == 0:
+        # dominant kernel for the roofline: scaled INT8 A@B.T (the training forward layout)
+        avg_ms, med_ms = time_kernel(lambda: gn_kernels.scaled_mm(*cases[("int8", "A@B.T")]), iters=50)
+        achieved = 2 * S ** 3 / (avg_ms * 1e-3) * 1e-12
+        out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_DENSE_8BIT_TOPS, "unit": "TFLOP/s",
+                           "frac": round(achieved / PEAK_DENSE_8BIT_TOPS, 4), "traffic": None,
+                           "kernel": "gemm_kernel<256x256, int8, A K-major, B K-major, row/col epilogue>",
+                           "avg_launch_us": round(avg_ms * 1e3, 2), "median_launch_us": round(med_ms * 1e3, 2),
+                           "algorithmic_ops_per_launch": 2 * S ** 3}
+        if not args.no_detail:
+            detail = {}
+            for (d, l), a in cases.items():
+                avg, _ = time_kernel(lambda a=a: gn_kernels.scaled_mm(*a), iters=20)
+                detail[f"{d} {l} {S}"] = round(2 * S ** 3 / (avg * 1e-3) * 1e-12, 1)
+            for s in (1024, 2048):
+                small = make_inputs(s, dev)
+                for d in ("int8", "fp8"):
+                    for l in LAYOUTS:
+                        avg, _ = time_kernel(lambda a=small[(d, l)]: gn_kernels.scaled_mm(*a), iters=20)
+                        detail[f"{d} {l} {s}"] = round(2 * s ** 3 / (avg * 1e-3) * 1e-12, 1)
+            out["detail_tops"] = detail
+            # quantize pass: algorithmic bytes = 3*R*C + 2*R (read bf16 once, write int8 + bf16 scales)
+            from subclasses import quantize_int8
+
+            x = torch.randn(S, S, device=dev).bfloat16()
+            q = {}
+            for name, dim in (("rowwise (reduce contiguous dim)", 1), ("colwise (reduce strided dim)", 0)):
+                avg, _ = time_kernel(lambda dim=dim: quantize_int8(x, dim=dim), iters=30)
+                gbs = (3 * S * S + 2 * S) / (avg * 1e-3) * 1e-9
+                q[name] = {"GB/s": round(gbs, 1), "frac_of_8TBs": round(gbs / PEAK_HBM_GBS, 4), "us": round(avg * 1e3, 2)}
+            out["detail_quantize_4096x4096_bf16"] = q
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

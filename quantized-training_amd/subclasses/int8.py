@@ -161,6 +161,7 @@ _INT8_DISPATCH = {
     aten.copy_.default: _i8_copy_,
     aten.addcdiv_.default: _i8_inplace_update,
     aten.add_.Tensor: _i8_inplace_update,
+    aten.mul_.Tensor: _i8_inplace_update,    # AdamW's decoupled weight decay (not handled by the reference)
 }
 
 

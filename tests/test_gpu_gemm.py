@@ -1,0 +1,236 @@
+"""GPU parity of the MFMA GEMM kernels through the gn_kernels ops -> C ABI: int32 accumulators and
+fp32 scaled outputs bit-exact against reference-generated goldens and the CPU oracle in all operand
+layouts and kernel variants; fp8 within the reference benchmark's tolerances; full-size (4096^3)
+checks through sampled rows/columns and epilogue-linearity properties."""
+import pytest
+import torch
+
+import gn_kernels
+import oracle
+from gn_kernels import _cabi
+from tests._util import FLOAT_DTYPES, FP8_DTYPES, LAYOUTS, bits_equal, load, t_from_bits, to_layout
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+VARIANTS = {"auto": -1, "tile256": 0, "tile128": 1, "generic": 2}
+
+
+@pytest.fixture(params=list(VARIANTS))
+def variant(request):
+    L = _cabi.load()
+    L.gnk_set_gemm_variant(VARIANTS[request.param])
+    yield request.param
+    L.gnk_set_gemm_variant(-1)
+
+
+def dev_layout(x, column_major):
+    return to_layout(x.to(DEV), column_major)
+
+
+def fp8_mag(A, B, sa=None, sb=None):
+    """sum_k |a_mk * b_kn| (times |scales|): the magnitude the fp8 MFMA's accumulation error scales with."""
+    a, b = A.float().abs().cpu(), B.float().abs().cpu()
+    if sa is not None:
+        M, K = a.shape
+        N = b.shape[1]
+        sa, sb = sa.float().abs().cpu(), sb.float().abs().cpu()
+        a = a * sa.repeat_interleave(M // sa.shape[0], 0).repeat_interleave(K // sa.shape[1], 1)
+        b = b * sb.repeat_interleave(K // sb.shape[0], 0).repeat_interleave(N // sb.shape[1], 1)
+    return a @ b
+
+
+def assert_fp8_close(got, want, mag):
+    """STATED TOLERANCE for fp8 products on MI355X:  |got - want| <= rtol*|want| + 5e-5 * sum_k|a*b| + 1e-5,
+    rtol = 1.6e-2 for bf16/fp16 outputs (the reference's assert_close default, benchmark_mm.py:128-145)
+    and 2e-3 for fp32 outputs.  The middle term is a hardware property: CDNA4's fp8 MFMAs (both
+    v_mfma_f32_16x16x32_fp8_fp8 and v_mfma_scale_f32_16x16x128_f8f6f4) sum their products with less
+    than fp32 precision -- measured max |err| / sum|a*b| = 1.4e-5 at K=128 on randn data
+    (tools/fp8_err.py), identical for both instructions -- so an output that nearly cancels can miss
+    a purely relative bound that NVIDIA's fp32-accumulating MMA meets."""
+    rtol = 2e-3 if got.dtype is torch.float32 else 1.6e-2
+    got, want = got.float().cpu(), want.float().cpu()
+    bound = rtol * want.abs() + 5e-5 * mag + 1e-5
+    bad = (got - want).abs() > bound
+    assert not bool(bad.any()), f"{int(bad.sum())} elements outside the fp8 tolerance; worst excess {((got - want).abs() - bound).max().item():.3e}"
+
+
+# ------------------------------------------------------------------------------- goldens
+@pytest.mark.parametrize("layout", list(LAYOUTS))
+def test_int8_mm_golden_bit_exact(layout, variant):
+    g = load("g2_g3_int8_mm.npz")
+    acm, bcm = LAYOUTS[layout]
+    A, B = dev_layout(torch.from_numpy(g["A"]), acm), dev_layout(torch.from_numpy(g["B"]), bcm)
+    C = gn_kernels.int8_mm(A, B)
+    assert C.dtype is torch.int32 and torch.equal(C.cpu(), torch.from_numpy(g["C_i32"]))
+
+
+@pytest.mark.parametrize("name", ["bf16", "f16", "f32"])
+@pytest.mark.parametrize("layout", list(LAYOUTS))
+def test_scaled_mm_int8_golden_bit_exact(layout, name, variant):
+    g = load("g2_g3_int8_mm.npz")
+    dt = FLOAT_DTYPES[name]
+    acm, bcm = LAYOUTS[layout]
+    A, B = dev_layout(torch.from_numpy(g["A"]), acm), dev_layout(torch.from_numpy(g["B"]), bcm)
+    rs, cs = t_from_bits(g[f"rs_{name}"], dt).to(DEV), t_from_bits(g[f"cs_{name}"], dt).to(DEV)
+    want32 = torch.from_numpy(g[f"C_scaled_{name}"])
+    out = gn_kernels.scaled_mm(A, B, rs, cs)
+    assert out.dtype is dt and bits_equal(out, want32.to(dt))          # kernel result == RNE(fp32 golden)
+    if name == "f32":
+        assert bits_equal(out, want32)
+    outs = gn_kernels.scaled_mm(A, B, rs, cs[:, :1].contiguous())         # COL_SCALE_SCALAR
+    assert bits_equal(outs, torch.from_numpy(g[f"C_scaled_scalar_{name}"]).to(dt))
+
+
+@pytest.mark.parametrize("layout", list(LAYOUTS))
+def test_tile_scaled_int8_deepseek_golden_bit_exact(layout, variant):
+    if variant == "tile256":
+        pytest.skip("tile-scaled epilogue has no 256x256 variant (uses the 128x128 tile)")
+    g = load("g4_tile_scaled_int8.npz")
+    acm, bcm = LAYOUTS[layout]
+    A, B = dev_layout(torch.from_numpy(g["ds_A"]), acm), dev_layout(torch.from_numpy(g["ds_B"]), bcm)
+    sA = dev_layout(t_from_bits(g["ds_sA"], torch.bfloat16), acm).float()
+    sB = dev_layout(t_from_bits(g["ds_sB"], torch.bfloat16), bcm).float()
+    assert bits_equal(gn_kernels.scaled_mm(A, B, sA, sB), torch.from_numpy(g["ds_C"]))      # fp32 scales -> fp32 out, exact
+    sAb, sBb = sA.bfloat16(), sB.bfloat16()
+    assert bits_equal(gn_kernels.scaled_mm(A, B, sAb, sBb), torch.from_numpy(g["ds_C"]).bfloat16())
+
+
+def test_tile_scaled_int8_jetfire_golden_bit_exact():
+    g = load("g4_tile_scaled_int8.npz")
+    A, B = torch.from_numpy(g["jf_A"]).to(DEV), dev_layout(torch.from_numpy(g["jf_B"]), True)
+    sA, sB = torch.from_numpy(g["jf_sA"]).to(DEV), torch.from_numpy(g["jf_sB"]).to(DEV)
+    assert bits_equal(gn_kernels.scaled_mm(A, B, sA, sB), torch.from_numpy(g["jf_C"]))
+
+
+@pytest.mark.parametrize("tag", ["e4m3_e4m3", "e5m2_e5m2", "e4m3_e5m2"])
+def test_fp8_goldens_within_reference_tolerance(tag, variant):
+    g = load("g5_fp8.npz")
+    an, bn = tag.split("_")
+    A = t_from_bits(g[f"A_{tag}"], FP8_DTYPES[an]).to(DEV)
+    B = dev_layout(t_from_bits(g[f"B_{tag}"], FP8_DTYPES[bn]), True)
+    rs, cs = t_from_bits(g["rs"], torch.bfloat16).to(DEV), t_from_bits(g["cs"], torch.bfloat16).to(DEV)
+    sA, sB = t_from_bits(g["sA"], torch.bfloat16).to(DEV), t_from_bits(g["sB"], torch.bfloat16).to(DEV)
+    C_scaled, C_tile, plain = (torch.from_numpy(g[f"C_{k}_{tag}"]) for k in ("scaled", "tile", "plain"))
+    mag, mag_s, mag_t = fp8_mag(A, B), fp8_mag(A, B, rs, cs), fp8_mag(A, B, sA, sB)
+    assert_fp8_close(gn_kernels.scaled_mm(A, B, rs, cs), C_scaled, mag_s)                       # bf16 out (benchmark_mm.py:142)
+    assert_fp8_close(gn_kernels.scaled_mm(A, B, rs.float(), cs.float()), C_scaled, mag_s)       # fp32 out
+    if variant != "tile256":
+        assert_fp8_close(gn_kernels.scaled_mm(A, B, sA, sB), C_tile, mag_t)
+        assert_fp8_close(gn_kernels.scaled_mm(A, B, sA.float(), sB.float()), C_tile, mag_t)
+    assert_fp8_close(gn_kernels._triton_mm(A, B, out_dtype=torch.bfloat16), plain, mag)         # benchmark_mm.py:129
+    if tag == "e4m3_e4m3":
+        assert_fp8_close(gn_kernels.fp8_mm(A, B), plain, mag)
+        # CUTLASS-named op: fp32 scales, (acc*col)*row, bf16 out (benchmark_mm.py:135-137)
+        out = gn_kernels.scaled_fp8_mm(A, B, rs.float(), cs.float())
+        assert out.dtype is torch.bfloat16
+        assert_fp8_close(out, C_scaled, mag_s)
+
+
+# ------------------------------------------------------------------------------- seeded random vs oracle
+@pytest.mark.parametrize("shape", [(256, 256, 128), (300, 200, 384), (512, 384, 1024), (130, 70, 256), (1, 16, 128), (100, 52, 200), (33, 17, 9)])
+@pytest.mark.parametrize("layout", list(LAYOUTS))
+def test_int8_paths_vs_oracle(shape, layout):
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M * 1000 + N)
+    acm, bcm = LAYOUTS[layout]
+    A = to_layout(torch.randint(-128, 128, (M, K), dtype=torch.int8, generator=g), acm)
+    B = to_layout(torch.randint(-128, 128, (K, N), dtype=torch.int8, generator=g), bcm)
+    rs = torch.randn(M, 1, generator=g).div(128).bfloat16()
+    cs = torch.randn(1, N, generator=g).div(128).bfloat16()
+    Ad, Bd = dev_layout(A, acm), dev_layout(B, bcm)
+    assert Ad.stride() == A.stride() and Bd.stride() == B.stride()
+    assert torch.equal(gn_kernels.int8_mm(Ad, Bd).cpu(), oracle.int8_mm(A, B))
+    assert bits_equal(gn_kernels.scaled_mm(Ad, Bd, rs.to(DEV), cs.to(DEV)), oracle.scaled_mm(A, B, rs, cs))
+    assert bits_equal(gn_kernels.scaled_mm(Ad, Bd, rs.float().to(DEV), cs.float().to(DEV)), oracle.scaled_mm(A, B, rs.float(), cs.float()))
+
+
+@pytest.mark.parametrize("blocks", [(1, 128, 128), (128, 128, 128), (1, 1, 128), (32, 32, 32), (16, 64, 64), (4, 8, 16)])
+def test_tile_scaled_int8_vs_oracle(blocks):
+    QM, QN, QK = blocks
+    M, N, K = 128, 256, 384
+    g = torch.Generator().manual_seed(QM + QN)
+    A = torch.randint(-128, 128, (M, K), dtype=torch.int8, generator=g)
+    B = to_layout(torch.randint(-128, 128, (K, N), dtype=torch.int8, generator=g), True)
+    sA = torch.randn(M // QM, K // QK, generator=g).div(128)
+    sB = torch.randn(K // QK, N // QN, generator=g).div(128)
+    got = gn_kernels.scaled_mm(A.to(DEV), dev_layout(B, True), sA.to(DEV), sB.to(DEV))
+    assert bits_equal(got, oracle.scaled_mm(A, B, sA, sB))
+
+
+@pytest.mark.parametrize("fmts", [("e4m3", "e4m3"), ("e5m2", "e4m3"), ("e4m3", "e5m2"), ("e5m2", "e5m2")])
+@pytest.mark.parametrize("layout", list(LAYOUTS))
+def test_fp8_paths_vs_oracle(fmts, layout, variant):
+    if variant == "tile256" and layout != "nt":
+        pytest.skip("covered by tile128 / auto")
+    M, N, K = 256, 384, 512
+    g = torch.Generator().manual_seed(11)
+    acm, bcm = LAYOUTS[layout]
+    A = to_layout(torch.randn(M, K, generator=g).to(FP8_DTYPES[fmts[0]]), acm)
+    B = to_layout(torch.randn(K, N, generator=g).to(FP8_DTYPES[fmts[1]]), bcm)
+    rs = torch.randn(M, 1, generator=g).div(128)
+    cs = torch.randn(1, N, generator=g).div(128)
+    Ad, Bd = dev_layout(A, acm), dev_layout(B, bcm)
+    assert_fp8_close(gn_kernels.scaled_mm(Ad, Bd, rs.to(DEV), cs.to(DEV)), oracle.scaled_mm(A, B, rs, cs), fp8_mag(A, B, rs, cs))
+    assert_fp8_close(gn_kernels._triton_mm(Ad, Bd, out_dtype=torch.float32), oracle.fp8_mm(A, B, out_dtype=torch.float32), fp8_mag(A, B))
+    assert_fp8_close(gn_kernels.scaled_mm(Ad, Bd, rs.bfloat16().to(DEV), cs.bfloat16().to(DEV)),
+                     oracle.scaled_mm(A, B, rs.bfloat16(), cs.bfloat16(), out_dtype=torch.float32), fp8_mag(A, B, rs, cs))
+
+
+def test_errors_surface_as_exceptions():
+    A = torch.zeros(4, 8, dtype=torch.int8, device=DEV)
+    with pytest.raises(RuntimeError):
+        torch.ops.gn_kernels.scaled_mm(A, A.T.contiguous(), torch.ones(4, 1, device=DEV, dtype=torch.float64), torch.ones(1, 4, device=DEV, dtype=torch.float64))
+    L = _cabi.load()
+    L.gnk_set_gemm_variant(0)
+    try:
+        with pytest.raises(RuntimeError, match="forced fast variant"):
+            gn_kernels.int8_mm(torch.zeros(33, 9, dtype=torch.int8, device=DEV), torch.zeros(9, 17, dtype=torch.int8, device=DEV))
+    finally:
+        L.gnk_set_gemm_variant(-1)
+    assert gn_kernels.int8_mm(torch.zeros(0, 8, dtype=torch.int8, device=DEV), torch.zeros(8, 4, dtype=torch.int8, device=DEV)).shape == (0, 4)
+
+
+# ------------------------------------------------------------------------------- benchmark size
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+def test_full_size_4096_int8(layout):
+    """benchmark_mm.py inputs at 4096^3: sampled rows x columns against the oracle (bit-exact) and the
+    fused epilogue against the unfused int32 result (bit-exact), per layout."""
+    torch.manual_seed(2025 * 2024)
+    S = 4096
+    acm, bcm = LAYOUTS[layout]
+    A = to_layout(torch.randint(-128, 127, (S, S), dtype=torch.int8, device=DEV), acm)
+    B = to_layout(torch.randint(-128, 127, (S, S), dtype=torch.int8, device=DEV), bcm)
+    rs = torch.randn(S, 1, device=DEV).div(128).bfloat16()
+    cs = torch.randn(1, S, device=DEV).div(128).bfloat16()
+    C = gn_kernels.int8_mm(A, B)
+    rows = torch.randperm(S)[:48].sort().values
+    cols = torch.randperm(S)[:48].sort().values
+    want = oracle.int8_mm(A[rows.to(DEV)].cpu().contiguous(), B[:, cols.to(DEV)].cpu().contiguous())
+    assert torch.equal(C[rows.to(DEV)][:, cols.to(DEV)].cpu(), want)
+    # checksum of checksums: column sums of C == (column sums of A) @ B in exact int64 arithmetic
+    colsum = C.sum(0, dtype=torch.int64)
+    want_colsum = (A.sum(0, dtype=torch.int64).double() @ B.double()).to(torch.int64)       # |values| < 2^53: exact in fp64
+    assert torch.equal(colsum, want_colsum)
+    out = gn_kernels.scaled_mm(A, B, rs, cs)
+    assert bits_equal(out, ((C.float() * rs.float()) * cs.float()).bfloat16())
+    torch.testing.assert_close(out[:64].float(), ((A[:64].float() * rs[:64].float()) @ (B.float() * cs.float())), atol=4e-4, rtol=1e-2)
+
+
+def test_full_size_4096_tile_scaled_and_fp8():
+    torch.manual_seed(2025 * 2024)
+    S = 4096
+    A = torch.randint(-128, 127, (S, S), dtype=torch.int8, device=DEV)
+    B = to_layout(torch.randint(-128, 127, (S, S), dtype=torch.int8, device=DEV), True)
+    tsA = torch.randn(S, S // 128, device=DEV).div(128).bfloat16()
+    tsB = to_layout(torch.randn(S // 128, S // 128, device=DEV).div(128).bfloat16(), True)
+    out = gn_kernels.scaled_mm(A, B, tsA, tsB)
+    rows = torch.arange(0, S, 97, device=DEV)
+    want = oracle.scaled_mm(A[rows].cpu().contiguous(), B[:, :256].cpu(), tsA[rows].cpu().contiguous(), tsB[:, :2].cpu())
+    assert bits_equal(out[rows][:, :256], want)
+    A8 = torch.randn(S, S, device=DEV).to(torch.float8_e4m3fn)
+    B8 = to_layout(torch.randn(S, S, device=DEV).to(torch.float8_e4m3fn), True)
+    rs = torch.randn(S, 1, device=DEV).div(128).bfloat16()
+    cs = torch.randn(1, S, device=DEV).div(128).bfloat16()
+    out8 = gn_kernels.scaled_mm(A8, B8, rs, cs)
+    want8 = (A8[:128].float() * rs[:128].float()) @ (B8.float() * cs.float())                   # scaled_mm_ref, benchmark_mm.py:46-50
+    assert_fp8_close(out8[:128], want8, fp8_mag(A8[:128], B8, rs[:128], cs))
