@@ -126,6 +126,13 @@ int gnk_fp8_mm(const void *A, int a_dtype, const void *B, int b_dtype, void *C, 
  */
 int gnk_set_gemm_variant(int variant);
 
+/*
+ * Timing-ablation hook (no reference counterpart; results are WRONG while flags != 0): bit 0 drops the
+ * main loop's LDS-DMA loads, bit 1 the MFMAs, bit 2 the LDS fragment reads of the 256 x 256 kernel.
+ * Used by tools/ablate.py to attribute kernel time.  Returns the previous flags.
+ */
+int gnk_set_debug_flags(int flags);
+
 #ifdef __cplusplus
 }
 #endif

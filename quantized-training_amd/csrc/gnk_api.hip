@@ -7,6 +7,7 @@
 // ------------------------------------------------------------------ error plumbing
 static thread_local char g_err[512] = "";
 static thread_local int g_forced_variant = -1;
+static thread_local int g_debug_flags = 0;
 
 int gnk_fail(int code, const char *fmt, ...) {
     va_list ap;
@@ -52,6 +53,12 @@ extern "C" int gnk_set_gemm_variant(int variant) {
     return old;
 }
 
+extern "C" int gnk_set_debug_flags(int flags) {
+    const int old = g_debug_flags;
+    g_debug_flags = flags;
+    return old;
+}
+
 // ------------------------------------------------------------------ GEMM dispatch
 namespace {
 
@@ -79,7 +86,7 @@ OperandLayout classify(const void *ptr, int64_t ext, int64_t K, int64_t s_mn, in
 }
 
 gnk_gemm_launcher pick_launcher(int op, int fa, int fb, int variant) {
-    if (op == OP_I8) return variant == GNK_VARIANT_256 ? gnk_launch_i8_v0 : gnk_launch_i8_v1;
+    if (op == OP_I8) return variant == GNK_VARIANT_256 ? gnk_launch_i8_v0 : variant == GNK_VARIANT_256_SIMPLE ? gnk_launch_i8_v3 : gnk_launch_i8_v1;
     static const gnk_gemm_launcher f8[2][2][2] = {
         {{gnk_launch_f8_00_v0, gnk_launch_f8_00_v1}, {gnk_launch_f8_01_v0, gnk_launch_f8_01_v1}},
         {{gnk_launch_f8_10_v0, gnk_launch_f8_10_v1}, {gnk_launch_f8_11_v0, gnk_launch_f8_11_v1}}};
@@ -118,7 +125,8 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
     const OperandLayout lb = classify(c.B, c.N, c.K, c.sbn, c.sbk);
     const bool fast_ok = la.fast && lb.fast && c.K >= GNK_BK && c.K % GNK_BK == 0 && (c.epi != EPI_TILE || c.QK == GNK_BK) &&
                          c.M < (1LL << 31) && c.N < (1LL << 31) && ((c.M + 127) / 128) * ((c.N + 127) / 128) < (1LL << 31);
-    if (variant < 0 || variant > GNK_VARIANT_GENERIC) {
+    if (variant == GNK_VARIANT_256_SIMPLE && op != OP_I8) variant = GNK_VARIANT_256;
+    if (variant < 0 || variant > GNK_VARIANT_256_SIMPLE) {
         if (!fast_ok) variant = GNK_VARIANT_GENERIC;
         else {
             // 256^2 tiles once they alone fill most of the chip, else 128^2 (2 workgroups / CU)
@@ -145,6 +153,7 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
     p.M = c.M; p.N = c.N; p.K = c.K; p.lda = la.ld; p.ldb = lb.ld;
     p.ssam = c.ssam; p.ssak = c.ssak; p.ssbk = c.ssbk; p.ssbn = c.ssbn; p.QM = c.QM; p.QN = c.QN;
     p.out_dtype = c.out_dtype; p.scale_dtype = c.scale_dtype; p.col_scalar = c.col_scalar; p.order = c.order;
+    p.debug = g_debug_flags;
     return pick_launcher(op, fa, fb, variant)(la.kmajor, lb.kmajor, c.epi, p, st);
 }
 

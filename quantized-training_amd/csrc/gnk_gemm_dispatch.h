@@ -1,12 +1,14 @@
 // gnk_gemm_dispatch.h -- launcher table shared by the instantiation units and gnk_api.hip.
 #pragma once
 #include "gnk_gemm_kernel.h"
+#include "gnk_gemm_pp.h"
 
 // GEMM tile variants (gnk_set_gemm_variant):
-//   0: 256 x 256 tile, 8 waves (2 x 4), 128 KiB LDS, 1 workgroup / CU   -- large problems
-//   1: 128 x 128 tile, 4 waves (2 x 2),  64 KiB LDS, 2 workgroups / CU  -- mid-size problems
+//   0: 256 x 256 tile, 8 waves, ping-pong phase schedule (gnk_gemm_pp.h), 1 workgroup / CU -- large problems
+//   1: 128 x 128 tile, 4 waves (2 x 2), two-buffer loop, 64 KiB LDS, 2 workgroups / CU    -- mid-size problems
 //   2: generic 64 x 64 kernel (any strides / sizes; the fallback)
-enum { GNK_VARIANT_256 = 0, GNK_VARIANT_128 = 1, GNK_VARIANT_GENERIC = 2, GNK_NUM_FAST_VARIANTS = 2 };
+//   3: 256 x 256 tile, 8 waves, two-buffer loop (the pre-ping-pong kernel; int8 only, kept for A/B timing)
+enum { GNK_VARIANT_256 = 0, GNK_VARIANT_128 = 1, GNK_VARIANT_GENERIC = 2, GNK_VARIANT_256_SIMPLE = 3 };
 
 // fp8 format codes as the MFMA's cbsz/blgp fields want them
 enum { F8_E4M3 = 0, F8_E5M2 = 1 };
@@ -18,6 +20,7 @@ typedef int (*gnk_gemm_launcher)(bool a_kmajor, bool b_kmajor, int epi, const Ge
 
 GNK_DECLARE_LAUNCHER(gnk_launch_i8_v0);
 GNK_DECLARE_LAUNCHER(gnk_launch_i8_v1);
+GNK_DECLARE_LAUNCHER(gnk_launch_i8_v3);
 GNK_DECLARE_LAUNCHER(gnk_launch_f8_00_v0);
 GNK_DECLARE_LAUNCHER(gnk_launch_f8_01_v0);
 GNK_DECLARE_LAUNCHER(gnk_launch_f8_10_v0);
@@ -36,6 +39,21 @@ GNK_DECLARE_LAUNCHER(gnk_launch_f8_11_v1);
         case EPI_PLAIN: return gnk_gemm::launch<GemmCfg<BM, BN, WM, WN, AK, BK, OP, FA, FB, EPI_PLAIN>>(p, st);   \
         case EPI_ROWCOL: return gnk_gemm::launch<GemmCfg<BM, BN, WM, WN, AK, BK, OP, FA, FB, EPI_ROWCOL>>(p, st); \
         default: return gnk_gemm::launch<GemmCfg<TBM, TBN, TWM, TWN, AK, BK, OP, FA, FB, EPI_TILE>>(p, st);       \
+        }                                                                                                   \
+    }                                                                                                       \
+    int NAME(bool a_kmajor, bool b_kmajor, int epi, const GemmParams &p, hipStream_t st) {                  \
+        if (a_kmajor) return b_kmajor ? NAME##_l<true, true>(epi, p, st) : NAME##_l<true, false>(epi, p, st); \
+        return b_kmajor ? NAME##_l<false, true>(epi, p, st) : NAME##_l<false, false>(epi, p, st);           \
+    }
+
+// Variant 0: ping-pong 256 x 256 kernel for the plain / row-col epilogues, 128 x 128 two-buffer kernel
+// for the tile-scaled one.
+#define GNK_DEFINE_LAUNCHER_PP(NAME, OP, FA, FB)                                                            \
+    template <bool AK, bool BK> static int NAME##_l(int epi, const GemmParams &p, hipStream_t st) {         \
+        switch (epi) {                                                                                      \
+        case EPI_PLAIN: return gnk_gemm::launch_pp<GemmCfg<256, 256, 2, 4, AK, BK, OP, FA, FB, EPI_PLAIN>>(p, st);   \
+        case EPI_ROWCOL: return gnk_gemm::launch_pp<GemmCfg<256, 256, 2, 4, AK, BK, OP, FA, FB, EPI_ROWCOL>>(p, st); \
+        default: return gnk_gemm::launch<GemmCfg<128, 128, 2, 2, AK, BK, OP, FA, FB, EPI_TILE>>(p, st);     \
         }                                                                                                   \
     }                                                                                                       \
     int NAME(bool a_kmajor, bool b_kmajor, int epi, const GemmParams &p, hipStream_t st) {                  \

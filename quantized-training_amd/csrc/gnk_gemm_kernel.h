@@ -40,6 +40,7 @@ struct GemmParams {
     int64_t QM, QN;                   // tile-scale block sizes along M and N (QK == 128)
     int out_dtype, scale_dtype, col_scalar, order;
     int grid_m, grid_n;
+    int debug;        // timing-ablation flags (gnk_set_debug_flags): 1 = no LDS-DMA in the main loop, 2 = no MFMA, 4 = no LDS reads
 };
 
 template <int BM_, int BN_, int WM_, int WN_, bool AK_, bool BK_, int OP_, int FA_, int FB_, int EPI_>
@@ -79,17 +80,21 @@ __device__ __forceinline__ void tile_of_block(int grid_m, int grid_n, int &tm, i
 }
 
 // ------------------------------------------------------------------------------ staging
-// Per-lane source pointers of this wave's 1-KiB pieces of one operand tile.
+// This wave's 1-KiB pieces of one operand tile: a wave-uniform base pointer (SGPRs, advanced once per
+// K-step) plus one 32-bit byte offset per piece and lane (constant over the whole K loop), so the
+// LDS-DMA loads use the saddr + voffset form and cost no per-step address VALU.
 template <bool KMAJOR, int ROWS, int NW>
 struct Stager {
     static constexpr int NP = ROWS / 8 / NW;   // pieces per wave
-    const char *src[NP];
+    const char *base;                          // tile origin at the current K-step (wave-uniform)
+    unsigned off[NP];                          // per-lane byte offset of each piece from `base`
     int64_t step;                              // bytes to advance per K-step
 
-    // base: operand pointer; ld: leading dimension; r0: first row (m0 / n0) of the tile;
-    // extent: M or N (rows are clamped so that every lane reads valid memory; clamped rows only
-    // feed output elements that the epilogue masks).
-    __device__ __forceinline__ void init(const char *base, int64_t ld, int64_t r0, int64_t extent, int wave, int lane) {
+    // ptr: operand pointer; ld: leading dimension; r0: first row (m0 / n0) of the tile; extent: M or N.
+    // Rows / column chunks past the extent are clamped so that every lane reads valid memory; they
+    // only feed output elements that the epilogue masks.  The host guarantees 256 * ld < 2^31.
+    __device__ __forceinline__ void init(const char *ptr, int64_t ld, int64_t r0, int64_t extent, int wave, int lane) {
+        base = KMAJOR ? ptr + r0 * ld : ptr + r0;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int pc = i * NW + wave;
@@ -97,27 +102,28 @@ struct Stager {
             if constexpr (KMAJOR) {
                 int r, c;
                 gnk_kmaj_stage_src(p, r, c);
-                int64_t row = r0 + r;
-                row = row < extent ? row : extent - 1;
-                src[i] = base + row * ld + 16 * c;
+                const int64_t rmax = extent - 1 - r0;
+                const int64_t row = r < rmax ? r : rmax;
+                off[i] = (unsigned)(row * ld + 16 * c);
             } else {
                 int k, c;
                 gnk_mnmaj_stage_src<ROWS>(p, k, c);
-                int64_t col = r0 + 16 * c;
-                col = col + 16 <= extent ? col : extent - 16;
-                src[i] = base + (int64_t)k * ld + col;
+                const int64_t cmax = extent - 16 - r0;
+                const int64_t col = 16 * c < cmax ? 16 * c : cmax;
+                off[i] = (unsigned)((int64_t)k * ld + col);
             }
         }
         step = KMAJOR ? (int64_t)GNK_BK : (int64_t)GNK_BK * ld;
     }
 
+    // issue this wave's pieces of the tile at `base` into the LDS tile, then move on to the next K-step
     __device__ __forceinline__ void issue(char *tile, int wave) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int pc = i * NW + wave;
-            __builtin_amdgcn_global_load_lds((const GNK_GLOBAL void *)src[i], (GNK_LDS void *)(tile + pc * 1024), 16, 0, 0);
-            src[i] += step;
+            __builtin_amdgcn_global_load_lds((const GNK_GLOBAL void *)(base + off[i]), (GNK_LDS void *)(tile + pc * 1024), 16, 0, 0);
         }
+        base += step;
     }
 };
 
@@ -269,6 +275,110 @@ __device__ __forceinline__ void epilogue(const GemmParams &p, typename AccT<Cfg:
     }
 }
 
+// Final fp32 value of accumulator element (i, j, r) of this lane after the fused scale epilogue.
+template <class Cfg> struct EpiScales {
+    float rs[Cfg::MT];
+    float cs[Cfg::NTL][4];
+    __device__ __forceinline__ void load(const GemmParams &p, int64_t mrow, int64_t ncol) {
+        if constexpr (Cfg::EPI == EPI_ROWCOL) {
+#pragma unroll
+            for (int i = 0; i < Cfg::MT; ++i) {
+                const int64_t m = mrow + 16 * i;
+                rs[i] = m < p.M ? gnk_load_scalar_rt(p.s0, p.scale_dtype, m) : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < Cfg::NTL; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t n = ncol + 16 * j + r;
+                    cs[j][r] = p.col_scalar ? gnk_load_scalar_rt(p.s1, p.scale_dtype, 0) : (n < p.N ? gnk_load_scalar_rt(p.s1, p.scale_dtype, n) : 0.f);
+                }
+        }
+    }
+    template <class AccT_>
+    __device__ __forceinline__ float value(const GemmParams &p, const AccT_ &acc, const v4f *accf, int i, int j, int r) const {
+        if constexpr (Cfg::EPI == EPI_TILE) return (*accf)[r];
+        float a;
+        if constexpr (Cfg::OP == OP_I8) a = (float)acc[r];   // v_cvt_f32_i32: RNE
+        else a = acc[r];
+        if constexpr (Cfg::EPI == EPI_PLAIN) return a;
+        return p.order == 0 ? __fmul_rn(__fmul_rn(a, rs[i]), cs[j][r]) : __fmul_rn(__fmul_rn(a, cs[j][r]), rs[i]);
+    }
+};
+
+// 2-byte outputs (bf16 / fp16), N % 8 == 0: stage the wave's WTM x 64 result tile through its own slice of
+// LDS (free once the K loop is over) so that global stores are 16 B per lane and whole 128-byte row
+// segments per 8 lanes.  A lane's natural 8-byte pieces (4 consecutive n of one m) are store-ISSUE bound:
+// 32 B per row and instruction measured 1.6 TB/s; whole-line stores run at the HBM write rate.
+// LDS image per wave: [WTM rows][128 B], 16-byte chunk c of row m kept at c ^ (m & 7) (conflict-free
+// ds_read_b128, 2-way ds_write_b64).
+template <class Cfg, int OUT>
+__device__ __forceinline__ void epilogue_lds(const GemmParams &p, typename AccT<Cfg::OP>::type (&acc)[Cfg::MT][Cfg::NTL],
+                                             v4f (*accf)[Cfg::EPI == EPI_TILE ? Cfg::NTL : 1], char *smem, int wave, int lane,
+                                             int64_t mwave, int64_t nwave) {
+    static_assert(Cfg::WTN == 64, "LDS-staged epilogue assumes a 64-column wave tile (128-byte rows)");
+    static_assert(Cfg::NW * Cfg::WTM * 128 <= Cfg::LDS_BYTES, "result tile must fit the operand buffers");
+    char *const region = smem + wave * (Cfg::WTM * 128);
+    const int g = lane >> 4, ml = lane & 15;
+    EpiScales<Cfg> sc;
+    sc.load(p, mwave + ml, nwave + 4 * g);
+#pragma unroll
+    for (int j = 0; j < Cfg::NTL; ++j)
+#pragma unroll
+        for (int i = 0; i < Cfg::MT; ++i) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = sc.value(p, acc[i][j], Cfg::EPI == EPI_TILE ? &accf[i][j] : nullptr, i, j, r);
+            v2i o;
+            if constexpr (OUT == GNK_BF16) {
+                o[0] = (int)((unsigned)gnk_f32_to_bf16(v[0]) | ((unsigned)gnk_f32_to_bf16(v[1]) << 16));
+                o[1] = (int)((unsigned)gnk_f32_to_bf16(v[2]) | ((unsigned)gnk_f32_to_bf16(v[3]) << 16));
+            } else {
+                o[0] = (int)((unsigned)gnk_f32_to_f16(v[0]) | ((unsigned)gnk_f32_to_f16(v[1]) << 16));
+                o[1] = (int)((unsigned)gnk_f32_to_f16(v[2]) | ((unsigned)gnk_f32_to_f16(v[3]) << 16));
+            }
+            const int row = 16 * i + ml;
+            *(GNK_LDS v2i *)(GNK_LDS char *)(region + row * 128 + (((2 * j + (g >> 1)) ^ (ml & 7)) << 4) + 8 * (g & 1)) = o;
+        }
+    // same wave wrote and reads its slice: LDS operations of one wave complete in order
+#pragma unroll
+    for (int it = 0; it < Cfg::WTM / 8; ++it) {
+        const int row = it * 8 + (lane >> 3), c = lane & 7;
+        const v4i d = *(const GNK_LDS v4i *)(const GNK_LDS char *)(region + row * 128 + ((c ^ (row & 7)) << 4));
+        const int64_t m = mwave + row, n = nwave + 8 * c;
+        if (m < p.M && n < p.N) *(v4i *)((unsigned short *)p.C + m * p.N + n) = d;
+    }
+}
+
+// Epilogue entry shared by the kernels.  All LDS tile reads of the workgroup must have retired
+// (barrier) before the call.
+template <class Cfg>
+__device__ __forceinline__ void run_epilogue(const GemmParams &p, typename AccT<Cfg::OP>::type (&acc)[Cfg::MT][Cfg::NTL],
+                                             v4f (*accf)[Cfg::EPI == EPI_TILE ? Cfg::NTL : 1], char *smem, int wave, int lane,
+                                             int64_t mwave, int64_t nwave) {
+    const int64_t mrow = mwave + (lane & 15), ncol = nwave + 4 * (lane >> 4);
+    const bool aligned16 = ((uintptr_t)p.C & 15) == 0;
+    const bool vec_ok = (p.N % 4 == 0) && aligned16;
+    if constexpr (Cfg::EPI == EPI_PLAIN && Cfg::OP == OP_I8) {
+        if (vec_ok) epilogue<Cfg, GNK_I32, true>(p, acc, accf, mrow, ncol);
+        else epilogue<Cfg, GNK_I32, false>(p, acc, accf, mrow, ncol);
+    } else {
+        const bool lds_ok = (p.N % 8 == 0) && aligned16;
+        if (p.out_dtype == GNK_BF16) {
+            if (lds_ok) epilogue_lds<Cfg, GNK_BF16>(p, acc, accf, smem, wave, lane, mwave, nwave);
+            else if (vec_ok) epilogue<Cfg, GNK_BF16, true>(p, acc, accf, mrow, ncol);
+            else epilogue<Cfg, GNK_BF16, false>(p, acc, accf, mrow, ncol);
+        } else if (p.out_dtype == GNK_F16) {
+            if (lds_ok) epilogue_lds<Cfg, GNK_F16>(p, acc, accf, smem, wave, lane, mwave, nwave);
+            else if (vec_ok) epilogue<Cfg, GNK_F16, true>(p, acc, accf, mrow, ncol);
+            else epilogue<Cfg, GNK_F16, false>(p, acc, accf, mrow, ncol);
+        } else {
+            if (vec_ok) epilogue<Cfg, GNK_F32, true>(p, acc, accf, mrow, ncol);
+            else epilogue<Cfg, GNK_F32, false>(p, acc, accf, mrow, ncol);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------ the kernel
 template <class Cfg>
 __global__ void __launch_bounds__(Cfg::NT) gemm_kernel(const GemmParams p) {
@@ -368,22 +478,8 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_kernel(const GemmParams p) {
     }
 
     // ------------------------------------------------------------------ epilogue
-    const bool vec_ok = (p.N % 4 == 0) && (((uintptr_t)p.C & 15) == 0);
-    if constexpr (Cfg::EPI == EPI_PLAIN && Cfg::OP == OP_I8) {
-        if (vec_ok) epilogue<Cfg, GNK_I32, true>(p, acc, accf, mrow, ncol);
-        else epilogue<Cfg, GNK_I32, false>(p, acc, accf, mrow, ncol);
-    } else {
-        if (p.out_dtype == GNK_BF16) {
-            if (vec_ok) epilogue<Cfg, GNK_BF16, true>(p, acc, accf, mrow, ncol);
-            else epilogue<Cfg, GNK_BF16, false>(p, acc, accf, mrow, ncol);
-        } else if (p.out_dtype == GNK_F16) {
-            if (vec_ok) epilogue<Cfg, GNK_F16, true>(p, acc, accf, mrow, ncol);
-            else epilogue<Cfg, GNK_F16, false>(p, acc, accf, mrow, ncol);
-        } else {
-            if (vec_ok) epilogue<Cfg, GNK_F32, true>(p, acc, accf, mrow, ncol);
-            else epilogue<Cfg, GNK_F32, false>(p, acc, accf, mrow, ncol);
-        }
-    }
+    __syncthreads();   // every wave is done reading the operand tiles: LDS is free for the result staging
+    run_epilogue<Cfg>(p, acc, accf, smem, wave, lane, m0 + wm * Cfg::WTM, n0 + wn * Cfg::WTN);
 }
 
 template <class Cfg> int launch(const GemmParams &p0, hipStream_t st) {
