@@ -86,7 +86,11 @@ OperandLayout classify(const void *ptr, int64_t ext, int64_t K, int64_t s_mn, in
 }
 
 gnk_gemm_launcher pick_launcher(int op, int fa, int fb, int variant) {
-    if (op == OP_I8) return variant == GNK_VARIANT_256 ? gnk_launch_i8_v0 : variant == GNK_VARIANT_256_SIMPLE ? gnk_launch_i8_v3 : gnk_launch_i8_v1;
+    if (op == OP_I8)
+        return variant == GNK_VARIANT_256 ? gnk_launch_i8_v0
+               : variant == GNK_VARIANT_256_SIMPLE ? gnk_launch_i8_v3
+               : variant == GNK_VARIANT_256_PP8 ? gnk_launch_i8_v4
+                                                : gnk_launch_i8_v1;
     static const gnk_gemm_launcher f8[2][2][2] = {
         {{gnk_launch_f8_00_v0, gnk_launch_f8_00_v1}, {gnk_launch_f8_01_v0, gnk_launch_f8_01_v1}},
         {{gnk_launch_f8_10_v0, gnk_launch_f8_10_v1}, {gnk_launch_f8_11_v0, gnk_launch_f8_11_v1}}};
@@ -123,17 +127,20 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
     int variant = g_forced_variant;
     const OperandLayout la = classify(c.A, c.M, c.K, c.sam, c.sak);
     const OperandLayout lb = classify(c.B, c.N, c.K, c.sbn, c.sbk);
-    const bool fast_ok = la.fast && lb.fast && c.K >= GNK_BK && c.K % GNK_BK == 0 && (c.epi != EPI_TILE || c.QK == GNK_BK) &&
-                         c.M < (1LL << 31) && c.N < (1LL << 31) && ((c.M + 127) / 128) * ((c.N + 127) / 128) < (1LL << 31);
-    if (variant == GNK_VARIANT_256_SIMPLE && op != OP_I8) variant = GNK_VARIANT_256;
-    if (variant < 0 || variant > GNK_VARIANT_256_SIMPLE) {
-        if (!fast_ok) variant = GNK_VARIANT_GENERIC;
-        else {
-            // 256^2 tiles once they alone fill most of the chip, else 128^2 (2 workgroups / CU)
-            const int64_t big_tiles = ((c.M + 255) / 256) * ((c.N + 255) / 256);
-            variant = (c.epi != EPI_TILE && big_tiles * 10 >= (int64_t)gnk_num_cus() * 8) ? GNK_VARIANT_256 : GNK_VARIANT_128;
-        }
-    } else if (variant != GNK_VARIANT_GENERIC && !fast_ok) {
+    const bool fast_layout = la.fast && lb.fast && c.M < (1LL << 31) && c.N < (1LL << 31) && la.ld * 256 < (1LL << 31) &&
+                             lb.ld * 256 < (1LL << 31) && ((c.M + 127) / 128) * ((c.N + 127) / 128) < (1LL << 31);
+    // 4-stage 256^2 kernel: 64-k stages, no tile-scaled epilogue; the two-buffer kernels step 128 k
+    const bool ok_pp2 = fast_layout && c.K >= 64 && c.K % 64 == 0 && c.epi != EPI_TILE;
+    const bool ok_128 = fast_layout && c.K >= GNK_BK && c.K % GNK_BK == 0 && (c.epi != EPI_TILE || c.QK == GNK_BK);
+    if ((variant == GNK_VARIANT_256_SIMPLE || variant == GNK_VARIANT_256_PP8) && (op != OP_I8 || c.epi == EPI_TILE)) variant = GNK_VARIANT_256;
+    if (variant == GNK_VARIANT_256 && c.epi == EPI_TILE) variant = GNK_VARIANT_128;
+    if (variant < 0 || variant > GNK_VARIANT_LAST) {
+        // 256^2 tiles once they alone fill most of the chip, else 128^2 (2 workgroups / CU)
+        const int64_t big_tiles = ((c.M + 255) / 256) * ((c.N + 255) / 256);
+        if (ok_pp2 && (big_tiles * 10 >= (int64_t)gnk_num_cus() * 8 || !ok_128)) variant = GNK_VARIANT_256;
+        else if (ok_128) variant = GNK_VARIANT_128;
+        else variant = GNK_VARIANT_GENERIC;
+    } else if (variant != GNK_VARIANT_GENERIC && !(variant == GNK_VARIANT_256 ? ok_pp2 : ok_128)) {
         return gnk_fail(GNK_ERR_UNSUPPORTED, "%s: forced fast variant %d cannot take these strides / sizes", name, variant);
     }
 

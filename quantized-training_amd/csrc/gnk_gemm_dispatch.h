@@ -2,13 +2,15 @@
 #pragma once
 #include "gnk_gemm_kernel.h"
 #include "gnk_gemm_pp.h"
+#include "gnk_gemm_pp2.h"
 
 // GEMM tile variants (gnk_set_gemm_variant):
-//   0: 256 x 256 tile, 8 waves, ping-pong phase schedule (gnk_gemm_pp.h), 1 workgroup / CU -- large problems
+//   0: 256 x 256 tile, 8 waves, four 64-k stages, 2-phase ping-pong (gnk_gemm_pp2.h), 1 workgroup / CU -- large problems
 //   1: 128 x 128 tile, 4 waves (2 x 2), two-buffer loop, 64 KiB LDS, 2 workgroups / CU    -- mid-size problems
 //   2: generic 64 x 64 kernel (any strides / sizes; the fallback)
-//   3: 256 x 256 tile, 8 waves, two-buffer loop (the pre-ping-pong kernel; int8 only, kept for A/B timing)
-enum { GNK_VARIANT_256 = 0, GNK_VARIANT_128 = 1, GNK_VARIANT_GENERIC = 2, GNK_VARIANT_256_SIMPLE = 3 };
+//   3: 256 x 256 tile, 8 waves, two-buffer loop (the first kernel; int8 only, kept for A/B timing)
+//   4: 256 x 256 tile, 8 waves, two 128-k buffers, 8-phase ping-pong (gnk_gemm_pp.h; int8 only, kept for A/B timing)
+enum { GNK_VARIANT_256 = 0, GNK_VARIANT_128 = 1, GNK_VARIANT_GENERIC = 2, GNK_VARIANT_256_SIMPLE = 3, GNK_VARIANT_256_PP8 = 4, GNK_VARIANT_LAST = 4 };
 
 // fp8 format codes as the MFMA's cbsz/blgp fields want them
 enum { F8_E4M3 = 0, F8_E5M2 = 1 };
@@ -21,6 +23,7 @@ typedef int (*gnk_gemm_launcher)(bool a_kmajor, bool b_kmajor, int epi, const Ge
 GNK_DECLARE_LAUNCHER(gnk_launch_i8_v0);
 GNK_DECLARE_LAUNCHER(gnk_launch_i8_v1);
 GNK_DECLARE_LAUNCHER(gnk_launch_i8_v3);
+GNK_DECLARE_LAUNCHER(gnk_launch_i8_v4);
 GNK_DECLARE_LAUNCHER(gnk_launch_f8_00_v0);
 GNK_DECLARE_LAUNCHER(gnk_launch_f8_01_v0);
 GNK_DECLARE_LAUNCHER(gnk_launch_f8_10_v0);
@@ -46,9 +49,23 @@ GNK_DECLARE_LAUNCHER(gnk_launch_f8_11_v1);
         return b_kmajor ? NAME##_l<false, true>(epi, p, st) : NAME##_l<false, false>(epi, p, st);           \
     }
 
-// Variant 0: ping-pong 256 x 256 kernel for the plain / row-col epilogues, 128 x 128 two-buffer kernel
-// for the tile-scaled one.
-#define GNK_DEFINE_LAUNCHER_PP(NAME, OP, FA, FB)                                                            \
+// Variant 0: 4-stage ping-pong 256 x 256 kernel for the plain / row-col epilogues, 128 x 128 two-buffer
+// kernel for the tile-scaled one.
+#define GNK_DEFINE_LAUNCHER_PP2(NAME, OP, FA, FB)                                                           \
+    template <bool AK, bool BK> static int NAME##_l(int epi, const GemmParams &p, hipStream_t st) {         \
+        switch (epi) {                                                                                      \
+        case EPI_PLAIN: return gnk_gemm::launch_pp2<gnk_gemm::PP2Cfg<AK, BK, OP, FA, FB, EPI_PLAIN>>(p, st);   \
+        case EPI_ROWCOL: return gnk_gemm::launch_pp2<gnk_gemm::PP2Cfg<AK, BK, OP, FA, FB, EPI_ROWCOL>>(p, st); \
+        default: return gnk_gemm::launch<GemmCfg<128, 128, 2, 2, AK, BK, OP, FA, FB, EPI_TILE>>(p, st);     \
+        }                                                                                                   \
+    }                                                                                                       \
+    int NAME(bool a_kmajor, bool b_kmajor, int epi, const GemmParams &p, hipStream_t st) {                  \
+        if (a_kmajor) return b_kmajor ? NAME##_l<true, true>(epi, p, st) : NAME##_l<true, false>(epi, p, st); \
+        return b_kmajor ? NAME##_l<false, true>(epi, p, st) : NAME##_l<false, false>(epi, p, st);           \
+    }
+
+// Variant 4: the 8-phase ping-pong kernel (two 128-k buffers).
+#define GNK_DEFINE_LAUNCHER_PP8(NAME, OP, FA, FB)                                                           \
     template <bool AK, bool BK> static int NAME##_l(int epi, const GemmParams &p, hipStream_t st) {         \
         switch (epi) {                                                                                      \
         case EPI_PLAIN: return gnk_gemm::launch_pp<GemmCfg<256, 256, 2, 4, AK, BK, OP, FA, FB, EPI_PLAIN>>(p, st);   \

@@ -1,0 +1,326 @@
+// gnk_gemm_pp2.h -- 256 x 256 four-stage "ping-pong" MFMA GEMM for 8-bit operands on gfx950.
+//
+// Measured on MI355X (tools/ablate*.py) the 8-phase kernel of gnk_gemm_pp.h spends, per 128 k:
+// 0.87-0.99 us in MFMAs, +0.25 us in its 8 barriers, +0.3 us waiting for LDS-DMA data whose
+// prefetch window (2 buffers of 64 KiB) is only one K-step deep -- while the L2 -> LDS path itself needs
+// 0.92 us per 64 KiB per CU at its ceiling (~70 GB/s per CU).  This kernel keeps the ping-pong idea and
+// changes the granularity:
+//   * a STAGE is 64 k (A 256 x 64 B + B 256 x 64 B = 32 KiB); four stages live in LDS, so three stages of
+//     LDS-DMA are in flight behind the one being read (>= 4 phases, ~1 us, of latency tolerance);
+//   * a stage is consumed in TWO phases: one group of four waves issues its whole stage of MFMAs
+//     (16 x v_mfma_i32_32x32x32_i8 or 8 x v_mfma_scale_f32_32x32x64_f8f6f4 = 512 matrix-pipe cycles) while
+//     the other group reads its next stage's fragments (12 x ds_read_b128 / 24 x ds_read_b64_tr_b8),
+//     issues its share of the LDS-DMA for stage s+4 and waits for stage s+2 -- 4 barriers per 128 k;
+//   * 32 x 32 MFMA tiles: K = 32 (int8) / K = 64 (fp8) per instruction, so a 64-k stage is a whole
+//     number of MFMAs for both operand types.
+// Per-group program (group 1 runs one barrier behind group 0):
+//     MFMA(s)  | barrier | LOAD frags(s+1); DMA stage s+4 -> buffer s & 3; vmcnt: stage s+2 landed | barrier
+// Buffer safety: stage s is read by group 0 in LOAD(s-1) and by group 1 one phase later; the DMA that
+// overwrites its buffer is issued in LOAD(s), at least one barrier after both.  Stage s+2 is first read
+// in LOAD(s+1), after every wave's own vmcnt in LOAD(s) and the barrier(s) that follow.
+#pragma once
+#include "gnk_gemm_kernel.h"
+
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+namespace gnk_gemm {
+
+template <bool AK_, bool BK_, int OP_, int FA_, int FB_, int EPI_>
+struct PP2Cfg {
+    static constexpr bool A_KMAJOR = AK_, B_KMAJOR = BK_;
+    static constexpr int OP = OP_, FA = FA_, FB = FB_, EPI = EPI_;
+    static constexpr int SK = 64;                       // k per stage
+    static constexpr int NST = 4;                       // stages in LDS
+    static constexpr int OPER_BYTES = 256 * SK;         // one operand, one stage
+    static constexpr int LDS_BYTES = 2 * NST * OPER_BYTES;   // 128 KiB
+    static_assert(EPI_ != EPI_TILE, "tile-scaled epilogue uses the two-buffer kernel");
+};
+
+template <int OP> struct Acc32;
+template <> struct Acc32<OP_I8> { typedef v16i type; };
+template <> struct Acc32<OP_F8> { typedef v16f type; };
+
+// This wave's two 1-KiB pieces of one operand stage (see Stager in gnk_gemm_kernel.h).
+template <bool KMAJOR> struct Stager64 {
+    const char *base;
+    unsigned off[2];
+    int64_t step;
+    __device__ __forceinline__ void init(const char *ptr, int64_t ld, int64_t r0, int64_t extent, int wave, int lane) {
+        base = KMAJOR ? ptr + r0 * ld : ptr + r0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = (i * 8 + wave) * 64 + lane;
+            if constexpr (KMAJOR) {
+                int r, c;
+                gnk_k64_stage_src(p, r, c);
+                const int64_t rmax = extent - 1 - r0;
+                const int64_t row = r < rmax ? r : rmax;
+                off[i] = (unsigned)(row * ld + 16 * c);
+            } else {
+                int k, c;
+                gnk_mn64_stage_src(p, k, c);
+                const int64_t cmax = extent - 16 - r0;
+                const int64_t col = 16 * c < cmax ? 16 * c : cmax;
+                off[i] = (unsigned)((int64_t)k * ld + col);
+            }
+        }
+        step = KMAJOR ? 64 : 64 * ld;
+    }
+    __device__ __forceinline__ void issue(char *stage, int wave) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const GNK_GLOBAL void *)(base + off[i]), (GNK_LDS void *)(stage + (i * 8 + wave) * 1024), 16, 0, 0);
+        base += step;
+    }
+};
+
+template <class Cfg> struct PP2 {
+    typedef typename Acc32<Cfg::OP>::type acc_t;
+
+    // 32 bytes of one lane for the 32-row fragment starting at row / column rb of the stage image
+    template <bool KMAJOR> static __device__ __forceinline__ v8i load_frag32(const char *stage, int rb, int lane) {
+        if constexpr (KMAJOR) {
+            const v4i lo = *(const GNK_LDS v4i *)(const GNK_LDS char *)(stage + gnk_k64_frag_offset(rb, 0, lane));
+            const v4i hi = *(const GNK_LDS v4i *)(const GNK_LDS char *)(stage + gnk_k64_frag_offset(rb, 1, lane));
+            return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        } else {
+            const int o = gnk_mn64_frag_offset(rb, 0, 0, lane);   // (half, t) move the k row by 32*half + 8*t: + 256 B per row
+            const v2i a = __builtin_amdgcn_ds_read_tr8_b64_v2i32((GNK_LDS v2i *)(stage + o));
+            const v2i b = __builtin_amdgcn_ds_read_tr8_b64_v2i32((GNK_LDS v2i *)(stage + o + 8 * 256));
+            const v2i c = __builtin_amdgcn_ds_read_tr8_b64_v2i32((GNK_LDS v2i *)(stage + o + 32 * 256));
+            const v2i d = __builtin_amdgcn_ds_read_tr8_b64_v2i32((GNK_LDS v2i *)(stage + o + 40 * 256));
+            return (v8i){a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+        }
+    }
+
+    static __device__ __forceinline__ void load_frags(const char *As, const char *Bs, v8i (&fa)[4], v8i (&fb)[2], int wm, int wn, int lane) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = load_frag32<Cfg::B_KMAJOR>(Bs, wn * 64 + 32 * j, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = load_frag32<Cfg::A_KMAJOR>(As, wm * 128 + 32 * i, lane);
+    }
+
+    // one stage of MFMAs: acc[i][j] (32 m x 32 n, held as D[n][m]) += B-frag(j) x A-frag(i)
+    static __device__ __forceinline__ void mfma_stage(acc_t (&acc)[4][2], const v8i (&fa)[4], const v8i (&fb)[2]) {
+        __builtin_amdgcn_s_setprio(1);
+        if constexpr (Cfg::OP == OP_I8) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const v4i a = kk == 0 ? __builtin_shufflevector(fa[i], fa[i], 0, 1, 2, 3) : __builtin_shufflevector(fa[i], fa[i], 4, 5, 6, 7);
+                        const v4i b = kk == 0 ? __builtin_shufflevector(fb[j], fb[j], 0, 1, 2, 3) : __builtin_shufflevector(fb[j], fb[j], 4, 5, 6, 7);
+                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b, a, acc[i][j], 0, 0, 0);
+                    }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[j], fa[i], acc[i][j], Cfg::FB, Cfg::FA, 0, 0x7f7f7f7f, 0,
+                                                                                 0x7f7f7f7f);   // E8M0 127 = 2^0
+        }
+        // pin the cluster to this phase (register-only ops are otherwise free to sink past the barriers)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(acc[i][j]));
+        __builtin_amdgcn_s_setprio(0);
+    }
+
+    static __device__ __forceinline__ void phase_barrier() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ------------------------------------------------------------------ epilogue (32 x 32 tile maps)
+    // lane: m = mwave + 32 i + (lane & 31);  n = nwave + 32 j + 8 g + 4 h + r  with reg = 4 g + r, h = lane >> 5
+    template <int SDT>
+    static __device__ __forceinline__ void load_scales(const GemmParams &p, float (&rs)[4], float (&cs)[2][4][4], int64_t mwave, int64_t nwave, int lane) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t m = mwave + 32 * i + (lane & 31);
+            rs[i] = gnk_load_scalar<SDT>(p.s0, m < p.M ? m : p.M - 1);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t n = nwave + 32 * j + 8 * g + 4 * (lane >> 5) + r;
+                    cs[j][g][r] = gnk_load_scalar<SDT>(p.s1, p.col_scalar ? 0 : (n < p.N ? n : p.N - 1));
+                }
+    }
+
+    static __device__ __forceinline__ float value(const GemmParams &p, const acc_t &a, int reg, float rs, float cs) {
+        float x;
+        if constexpr (Cfg::OP == OP_I8) x = (float)a[reg];   // v_cvt_f32_i32: RNE
+        else x = a[reg];
+        if constexpr (Cfg::EPI == EPI_PLAIN) return x;
+        return p.order == 0 ? __fmul_rn(__fmul_rn(x, rs), cs) : __fmul_rn(__fmul_rn(x, cs), rs);
+    }
+
+    template <int OUT, int MODE>   // MODE 0: LDS-staged 16-byte stores (2-byte outputs); 1: direct vector; 2: direct scalar
+    static __device__ __forceinline__ void epilogue(const GemmParams &p, acc_t (&acc)[4][2], char *smem, int wave, int lane, int64_t mwave, int64_t nwave) {
+        float rs[4], cs[2][4][4];
+        if constexpr (Cfg::EPI == EPI_ROWCOL) {
+            if (p.scale_dtype == GNK_BF16) load_scales<GNK_BF16>(p, rs, cs, mwave, nwave, lane);
+            else if (p.scale_dtype == GNK_F16) load_scales<GNK_F16>(p, rs, cs, mwave, nwave, lane);
+            else load_scales<GNK_F32>(p, rs, cs, mwave, nwave, lane);
+        }
+        const int ml = lane & 31, h = lane >> 5;
+        char *const region = smem + wave * (128 * 128);   // this wave's 128 rows x 128 B result slice
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if constexpr (OUT == GNK_I32) v[r] = __int_as_float(acc[i][j][4 * g + r]);
+                        else v[r] = value(p, acc[i][j], 4 * g + r, rs[i], cs[j][g][r]);
+                    }
+                    if constexpr (MODE == 0) {
+                        v2i o;
+                        if constexpr (OUT == GNK_BF16) {
+                            o[0] = (int)((unsigned)gnk_f32_to_bf16(v[0]) | ((unsigned)gnk_f32_to_bf16(v[1]) << 16));
+                            o[1] = (int)((unsigned)gnk_f32_to_bf16(v[2]) | ((unsigned)gnk_f32_to_bf16(v[3]) << 16));
+                        } else {
+                            o[0] = (int)((unsigned)gnk_f32_to_f16(v[0]) | ((unsigned)gnk_f32_to_f16(v[1]) << 16));
+                            o[1] = (int)((unsigned)gnk_f32_to_f16(v[2]) | ((unsigned)gnk_f32_to_f16(v[3]) << 16));
+                        }
+                        const int row = 32 * i + ml;
+                        *(GNK_LDS v2i *)(GNK_LDS char *)(region + row * 128 + (((4 * j + g) ^ (row & 7)) << 4) + 8 * h) = o;
+                    } else {
+                        store4<OUT, MODE == 1>(p.C, mwave + 32 * i + ml, nwave + 32 * j + 8 * g + 4 * h, p.M, p.N, v[0], v[1], v[2], v[3]);
+                    }
+                }
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int row = it * 8 + (lane >> 3), c = lane & 7;
+                const v4i d = *(const GNK_LDS v4i *)(const GNK_LDS char *)(region + row * 128 + ((c ^ (row & 7)) << 4));
+                const int64_t m = mwave + row, n = nwave + 8 * c;
+                if (m < p.M && n < p.N) *(v4i *)((unsigned short *)p.C + m * p.N + n) = d;
+            }
+        }
+    }
+};
+
+template <class Cfg>
+__global__ void __launch_bounds__(512) gemm_pp2_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef PP2<Cfg> K;
+    typedef typename K::acc_t acc_t;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    int tm, tn;
+    tile_of_block(p.grid_m, p.grid_n, tm, tn);
+    const int64_t m0 = (int64_t)tm * 256, n0 = (int64_t)tn * 256;
+
+    Stager64<Cfg::A_KMAJOR> sa;
+    Stager64<Cfg::B_KMAJOR> sb;
+    sa.init(p.A, p.lda, m0, p.M, wave, lane);
+    sb.init(p.B, p.ldb, n0, p.N, wave, lane);
+
+    acc_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+    v8i fa[4], fb[2];
+
+    const int ns = (int)(p.K / Cfg::SK);
+    char *const Abuf = smem, *const Bbuf = smem + Cfg::NST * Cfg::OPER_BYTES;
+
+    // prologue: stages 0..3 in flight, wait for stage 0 only
+    const int npro = ns < Cfg::NST ? ns : Cfg::NST;
+    for (int s = 0; s < npro; ++s) {
+        sa.issue(Abuf + s * Cfg::OPER_BYTES, wave);
+        sb.issue(Bbuf + s * Cfg::OPER_BYTES, wave);
+    }
+    if (npro == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (npro == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (npro == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    K::phase_barrier();
+    K::load_frags(Abuf, Bbuf, fa, fb, wm, wn, lane);
+    // stage 1 must have landed before the first LOAD phase reads it
+    if (npro == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (npro == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    K::phase_barrier();
+    if (wm == 1) K::phase_barrier();   // stagger: group 1 runs one phase behind group 0
+
+    for (int s = 0; s < ns; ++s) {
+        // ---- MFMA phase
+        K::mfma_stage(acc, fa, fb);
+        K::phase_barrier();
+        // ---- LOAD phase
+        if (s + 1 < ns) {
+            const int b = (s + 1) & 3;
+            K::load_frags(Abuf + b * Cfg::OPER_BYTES, Bbuf + b * Cfg::OPER_BYTES, fa, fb, wm, wn, lane);
+        }
+        if (s + 4 < ns) {
+            const int b = s & 3;
+            sa.issue(Abuf + b * Cfg::OPER_BYTES, wave);
+            sb.issue(Bbuf + b * Cfg::OPER_BYTES, wave);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // stages s+3, s+4 may stay in flight; s+2 has landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail: drain
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        K::phase_barrier();
+    }
+    if (wm == 0) K::phase_barrier();   // pay the stagger back so barrier counts match
+
+    // all LDS stage reads retired at the last barrier; each wave stages its result through its own LDS slice
+    const int64_t mwave = m0 + wm * 128, nwave = n0 + wn * 64;
+    const bool aligned16 = ((uintptr_t)p.C & 15) == 0;
+    const bool vec_ok = (p.N % 4 == 0) && aligned16, lds_ok = (p.N % 8 == 0) && aligned16;
+    if constexpr (Cfg::EPI == EPI_PLAIN && Cfg::OP == OP_I8) {
+        if (vec_ok) K::template epilogue<GNK_I32, 1>(p, acc, smem, wave, lane, mwave, nwave);
+        else K::template epilogue<GNK_I32, 2>(p, acc, smem, wave, lane, mwave, nwave);
+    } else if (p.out_dtype == GNK_BF16) {
+        if (lds_ok) K::template epilogue<GNK_BF16, 0>(p, acc, smem, wave, lane, mwave, nwave);
+        else if (vec_ok) K::template epilogue<GNK_BF16, 1>(p, acc, smem, wave, lane, mwave, nwave);
+        else K::template epilogue<GNK_BF16, 2>(p, acc, smem, wave, lane, mwave, nwave);
+    } else if (p.out_dtype == GNK_F16) {
+        if (lds_ok) K::template epilogue<GNK_F16, 0>(p, acc, smem, wave, lane, mwave, nwave);
+        else if (vec_ok) K::template epilogue<GNK_F16, 1>(p, acc, smem, wave, lane, mwave, nwave);
+        else K::template epilogue<GNK_F16, 2>(p, acc, smem, wave, lane, mwave, nwave);
+    } else {
+        if (vec_ok) K::template epilogue<GNK_F32, 1>(p, acc, smem, wave, lane, mwave, nwave);
+        else K::template epilogue<GNK_F32, 2>(p, acc, smem, wave, lane, mwave, nwave);
+    }
+}
+
+template <class Cfg> int launch_pp2(const GemmParams &p0, hipStream_t st) {
+    GemmParams p = p0;
+    p.grid_m = (int)((p.M + 255) / 256);
+    p.grid_n = (int)((p.N + 255) / 256);
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return gnk_fail(GNK_ERR_LAUNCH, "gemm: no current HIP device");
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute((const void *)gemm_pp2_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess)
+            return gnk_fail(GNK_ERR_LAUNCH, "gemm: cannot reserve %d bytes of LDS", Cfg::LDS_BYTES);
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((gemm_pp2_kernel<Cfg>), dim3((unsigned)(p.grid_m * p.grid_n)), dim3(512), Cfg::LDS_BYTES, st, p);
+    return gnk_check_launch("gemm (4-stage ping-pong)");
+}
+
+}  // namespace gnk_gemm

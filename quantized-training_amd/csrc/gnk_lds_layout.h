@@ -59,3 +59,32 @@ template <int L> GNK_HD int gnk_mnmaj_frag_offset(int rb, int ks, int lane) {
     const int g = lane >> 4, q = (lane & 15) >> 1, hb = lane & 1;
     return gnk_mnmaj_offset<L>(64 * ks + 16 * g + q, rb >> 4) + 8 * hb;
 }
+
+// =============================================================================================
+// 64-k stage images of the 4-stage kernel (gnk_gemm_pp2.h): one stage of an operand is 256 x 64 bytes
+// and feeds 32-row MFMA tiles (v_mfma_i32_32x32x32_i8 / v_mfma_scale_f32_32x32x64_f8f6f4).
+// MFMA slot convention (both operands, so the dot product is k-permutation safe): lane l serves tile row
+// (l & 31) and k-half h = l >> 5; its 32 bytes are [ k = 16h .. 16h+15 | k = 32+16h .. 32+16h+15 ],
+// i.e. 16-byte chunks h and 2+h of the row.  int8 issues two K=32 MFMAs (one per 16-byte half),
+// fp8 one K=64 MFMA on all 32 bytes.
+//
+//  * K-major stage  [256 rows][64 B]: chunk c (0..3) of row r at slot c ^ ((r >> 2) & 3).
+//  * MN-major stage [64 k][256 B]:    chunk c (0..15) of k-row k at slot c ^ ((k & 7) << 1).
+GNK_HD int gnk_k64_offset(int r, int c) { return r * 64 + ((c ^ ((r >> 2) & 3)) << 4); }
+GNK_HD void gnk_k64_stage_src(int p, int &r, int &c) {
+    r = p >> 2;
+    c = (p & 3) ^ ((r >> 2) & 3);
+}
+// ds_read_b128 #half (0, 1) of the fragment whose first row is rb
+GNK_HD int gnk_k64_frag_offset(int rb, int half, int lane) { return gnk_k64_offset(rb + (lane & 31), 2 * half + (lane >> 5)); }
+
+GNK_HD int gnk_mn64_offset(int k, int c) { return k * 256 + ((c ^ ((k & 7) << 1)) << 4); }
+GNK_HD void gnk_mn64_stage_src(int p, int &k, int &c) {
+    k = p >> 4;
+    c = (p & 15) ^ ((k & 7) << 1);
+}
+// ds_read_b64_tr_b8 #(half, t): k rows 32*half + 16h + 8t .. +7 of columns rb + 16*((l>>4)&1) .. +15
+GNK_HD int gnk_mn64_frag_offset(int rb, int half, int t, int lane) {
+    const int h = lane >> 5, blk = (lane >> 4) & 1, q = (lane & 15) >> 1, hb = lane & 1;
+    return gnk_mn64_offset(32 * half + 16 * h + 8 * t + q, (rb >> 4) + blk) + 8 * hb;
+}

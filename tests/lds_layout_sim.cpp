@@ -89,7 +89,70 @@ template <int L> void sim_mnmajor() {
             }
 }
 
+// ---- 64-k stage images of the 4-stage kernel (32-row MFMA tiles) ------------------------------------
+void sim_k64() {
+    const int ROWS = 256;
+    std::vector<Elem> lds(ROWS * 64, Elem{-1, -1});
+    std::set<int> seen;
+    for (int p = 0; p < ROWS * 4; ++p) {
+        int r, c;
+        gnk_k64_stage_src(p, r, c);
+        CHECK(r >= 0 && r < ROWS && c >= 0 && c < 4, "k64: stage p=%d out of range", p);
+        CHECK(seen.insert(r * 4 + c).second, "k64: (%d,%d) staged twice", r, c);
+        for (int b = 0; b < 16; ++b) lds[p * 16 + b] = Elem{r, 16 * c + b};
+    }
+    for (int rb = 0; rb < ROWS; rb += 32)
+        for (int half = 0; half < 2; ++half) {
+            int off[64];
+            for (int lane = 0; lane < 64; ++lane) {
+                off[lane] = gnk_k64_frag_offset(rb, half, lane);
+                for (int b = 0; b < 16; ++b) {
+                    Elem e = lds[off[lane] + b];
+                    CHECK(e.row == rb + (lane & 31) && e.k == 32 * half + 16 * (lane >> 5) + b, "k64 rb=%d half=%d lane=%d byte=%d: got (%d,%d)", rb, half, lane, b, e.row, e.k);
+                }
+            }
+            for (int g = 0; g < 4; ++g) {
+                std::set<int> slots;
+                for (int i = 0; i < 16; ++i) slots.insert((off[B128_GROUPS[g][i]] / 16) % 16);
+                CHECK(slots.size() == 16, "k64 rb=%d half=%d: b128 group %d has a bank conflict (%zu slots)", rb, half, g, slots.size());
+            }
+        }
+}
+
+void sim_mn64() {
+    std::vector<Elem> lds(64 * 256, Elem{-1, -1});
+    std::set<int> seen;
+    for (int p = 0; p < 64 * 16; ++p) {
+        int k, c;
+        gnk_mn64_stage_src(p, k, c);
+        CHECK(k >= 0 && k < 64 && c >= 0 && c < 16, "mn64: stage p=%d out of range", p);
+        CHECK(seen.insert(k * 16 + c).second, "mn64: (%d,%d) staged twice", k, c);
+        for (int b = 0; b < 16; ++b) lds[p * 16 + b] = Elem{16 * c + b, k};
+    }
+    for (int rb = 0; rb < 256; rb += 32)
+        for (int half = 0; half < 2; ++half)
+            for (int t = 0; t < 2; ++t) {
+                int addr[64];
+                for (int lane = 0; lane < 64; ++lane) addr[lane] = gnk_mn64_frag_offset(rb, half, t, lane);
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int grp = lane & ~15, i = lane & 15;
+                    for (int b = 0; b < 8; ++b) {
+                        Elem e = lds[addr[grp + 2 * b + (i >> 3)] + (i & 7)];
+                        const int want_n = rb + (lane & 31), want_k = 32 * half + 16 * (lane >> 5) + 8 * t + b;
+                        CHECK(e.row == want_n && e.k == want_k, "mn64 rb=%d half=%d t=%d lane=%d byte=%d: got (n=%d,k=%d) want (%d,%d)", rb, half, t, lane, b, e.row, e.k, want_n, want_k);
+                    }
+                }
+                for (int h = 0; h < 2; ++h) {
+                    std::set<int> slots;
+                    for (int i = 0; i < 32; ++i) slots.insert((addr[32 * h + i] / 8) % 32);
+                    CHECK(slots.size() == 32, "mn64 rb=%d half=%d t=%d: b64 half %d has a bank conflict (%zu slots)", rb, half, t, h, slots.size());
+                }
+            }
+}
+
 int main() {
+    sim_k64();
+    sim_mn64();
     sim_kmajor<128>();
     sim_kmajor<256>();
     sim_mnmajor<128>();

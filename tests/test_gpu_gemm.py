@@ -12,7 +12,7 @@ from tests._util import FLOAT_DTYPES, FP8_DTYPES, LAYOUTS, bits_equal, load, t_f
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-VARIANTS = {"auto": -1, "tile256": 0, "tile128": 1, "generic": 2, "tile256simple": 3}
+VARIANTS = {"auto": -1, "tile256": 0, "tile128": 1, "generic": 2, "tile256simple": 3, "tile256pp8": 4}
 
 
 @pytest.fixture(params=list(VARIANTS))
@@ -83,7 +83,7 @@ def test_scaled_mm_int8_golden_bit_exact(layout, name, variant):
 
 @pytest.mark.parametrize("layout", list(LAYOUTS))
 def test_tile_scaled_int8_deepseek_golden_bit_exact(layout, variant):
-    if variant in ("tile256", "tile256simple"):
+    if variant in ("tile256", "tile256simple", "tile256pp8"):
         pytest.skip("tile-scaled epilogue has no 256x256 variant (uses the 128x128 tile)")
     g = load("g4_tile_scaled_int8.npz")
     acm, bcm = LAYOUTS[layout]
@@ -114,7 +114,7 @@ def test_fp8_goldens_within_reference_tolerance(tag, variant):
     mag, mag_s, mag_t = fp8_mag(A, B), fp8_mag(A, B, rs, cs), fp8_mag(A, B, sA, sB)
     assert_fp8_close(gn_kernels.scaled_mm(A, B, rs, cs), C_scaled, mag_s)                       # bf16 out (benchmark_mm.py:142)
     assert_fp8_close(gn_kernels.scaled_mm(A, B, rs.float(), cs.float()), C_scaled, mag_s)       # fp32 out
-    if variant not in ("tile256", "tile256simple"):
+    if variant not in ("tile256", "tile256simple", "tile256pp8"):
         assert_fp8_close(gn_kernels.scaled_mm(A, B, sA, sB), C_tile, mag_t)
         assert_fp8_close(gn_kernels.scaled_mm(A, B, sA.float(), sB.float()), C_tile, mag_t)
     assert_fp8_close(gn_kernels._triton_mm(A, B, out_dtype=torch.bfloat16), plain, mag)         # benchmark_mm.py:129
@@ -160,7 +160,7 @@ def test_tile_scaled_int8_vs_oracle(blocks):
 @pytest.mark.parametrize("fmts", [("e4m3", "e4m3"), ("e5m2", "e4m3"), ("e4m3", "e5m2"), ("e5m2", "e5m2")])
 @pytest.mark.parametrize("layout", list(LAYOUTS))
 def test_fp8_paths_vs_oracle(fmts, layout, variant):
-    if variant == "tile256simple":
+    if variant in ("tile256simple", "tile256pp8"):
         pytest.skip("int8-only variant")
     M, N, K = 256, 384, 512
     g = torch.Generator().manual_seed(11)
@@ -174,6 +174,35 @@ def test_fp8_paths_vs_oracle(fmts, layout, variant):
     assert_fp8_close(gn_kernels._triton_mm(Ad, Bd, out_dtype=torch.float32), oracle.fp8_mm(A, B, out_dtype=torch.float32), fp8_mag(A, B))
     assert_fp8_close(gn_kernels.scaled_mm(Ad, Bd, rs.bfloat16().to(DEV), cs.bfloat16().to(DEV)),
                      oracle.scaled_mm(A, B, rs.bfloat16(), cs.bfloat16(), out_dtype=torch.float32), fp8_mag(A, B, rs, cs))
+
+
+@pytest.mark.parametrize("shape", [(256, 256, 64), (300, 520, 192), (512, 256, 320), (1, 8, 64), (257, 263, 448)])
+@pytest.mark.parametrize("layout", list(LAYOUTS))
+def test_four_stage_kernel_k64_multiples_and_ragged_edges(shape, layout):
+    """The 256 x 256 four-stage kernel forced onto K = 64 * odd, fewer stages than its pipeline depth and
+    ragged M / N (clamped staging rows, masked stores, scalar / vector / LDS-staged epilogues)."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    acm, bcm = LAYOUTS[layout]
+    if (acm and M % 16) or ((not bcm) and N % 16):
+        pytest.skip("fast path needs 16-byte aligned leading dimensions")
+    A = to_layout(torch.randint(-128, 128, (M, K), dtype=torch.int8, generator=g), acm)
+    B = to_layout(torch.randint(-128, 128, (K, N), dtype=torch.int8, generator=g), bcm)
+    rs = torch.randn(M, 1, generator=g).div(128).bfloat16()
+    cs = torch.randn(1, N, generator=g).div(128).bfloat16()
+    A8 = to_layout(torch.randn(M, K, generator=g).to(torch.float8_e4m3fn), acm)
+    B8 = to_layout(torch.randn(K, N, generator=g).to(torch.float8_e5m2), bcm)
+    L = _cabi.load()
+    L.gnk_set_gemm_variant(0)
+    try:
+        Ad, Bd = dev_layout(A, acm), dev_layout(B, bcm)
+        assert torch.equal(gn_kernels.int8_mm(Ad, Bd).cpu(), oracle.int8_mm(A, B))
+        assert bits_equal(gn_kernels.scaled_mm(Ad, Bd, rs.to(DEV), cs.to(DEV)), oracle.scaled_mm(A, B, rs, cs))
+        assert bits_equal(gn_kernels.scaled_mm(Ad, Bd, rs.float().to(DEV), cs.float().to(DEV)), oracle.scaled_mm(A, B, rs.float(), cs.float()))
+        got8 = gn_kernels.scaled_mm(dev_layout(A8, acm), dev_layout(B8, bcm), rs.float().to(DEV), cs.float().to(DEV))
+        assert_fp8_close(got8, oracle.scaled_mm(A8, B8, rs.float(), cs.float()), fp8_mag(A8, B8, rs, cs))
+    finally:
+        L.gnk_set_gemm_variant(-1)
 
 
 def test_errors_surface_as_exceptions():
