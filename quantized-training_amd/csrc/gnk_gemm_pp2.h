@@ -11,8 +11,11 @@
 //     (16 x v_mfma_i32_32x32x32_i8 or 8 x v_mfma_scale_f32_32x32x64_f8f6f4 = 512 matrix-pipe cycles) while
 //     the other group reads its next stage's fragments (12 x ds_read_b128 / 24 x ds_read_b64_tr_b8),
 //     issues its share of the LDS-DMA for stage s+4 and waits for stage s+2 -- 4 barriers per 128 k;
-//   * 32 x 32 MFMA tiles: K = 32 (int8) / K = 64 (fp8) per instruction, so a 64-k stage is a whole
-//     number of MFMAs for both operand types.
+//   * MFMA shapes whose K divides the 64-k stage: int8 v_mfma_i32_16x16x64_i8 (32 per wave and stage),
+//     fp8 v_mfma_scale_f32_32x32x64_f8f6f4 (8 per wave and stage; the 16x16 scaled form needs K = 128).
+//     Shape matters beyond cycle counts: with every CU issuing back-to-back MFMAs on random operands
+//     (tools/probe_mfma.hip) the chip holds 1.91 GHz on i32_16x16x64_i8 but 1.40 GHz on i32_32x32x32_i8
+//     (9.15 vs 22.9 ns per MFMA and wave: 3.67 vs 2.93 POPS chip-wide), so int8 uses the 16 x 16 shape.
 // Per-group program (group 1 runs one barrier behind group 0):
 //     MFMA(s)  | barrier | LOAD frags(s+1); DMA stage s+4 -> buffer s & 3; vmcnt: stage s+2 landed | barrier
 // Buffer safety: stage s is read by group 0 in LOAD(s-1) and by group 1 one phase later; the DMA that
@@ -75,8 +78,72 @@ template <bool KMAJOR> struct Stager64 {
     }
 };
 
-template <class Cfg> struct PP2 {
+__device__ __forceinline__ void pp2_phase_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// ---- int8: 16 x 16 x 64 MFMA tiles; wave tile 128 x 64 = 8 x 4 tiles, fragments of 16 rows x 64 k (16 B per lane)
+template <class Cfg> struct PP2I8 {
+    typedef GemmCfg<256, 256, 2, 4, Cfg::A_KMAJOR, Cfg::B_KMAJOR, OP_I8, 0, 0, Cfg::EPI> ECfg;   // epilogue maps of gnk_gemm_kernel.h
+    typedef v4i acc_arr[8][4];
+    typedef v4i fa_arr[8];
+    typedef v4i fb_arr[4];
+    static __device__ __forceinline__ void zero(acc_arr &acc) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (v4i){0, 0, 0, 0};
+    }
+    static __device__ __forceinline__ void finish(const GemmParams &p, acc_arr &acc, char *smem, int wave, int lane, int64_t mwave, int64_t nwave) {
+        v4f(*no_accf)[1] = nullptr;
+        run_epilogue<ECfg>(p, acc, no_accf, smem, wave, lane, mwave, nwave);
+    }
+    template <bool KMAJOR> static __device__ __forceinline__ v4i load_frag16(const char *stage, int rb, int lane) {
+        if constexpr (KMAJOR) {
+            return *(const GNK_LDS v4i *)(const GNK_LDS char *)(stage + gnk_k64_frag16_offset(rb, lane));
+        } else {
+            const int o = gnk_mn64_frag16_offset(rb, 0, lane);
+            const v2i lo = __builtin_amdgcn_ds_read_tr8_b64_v2i32((GNK_LDS v2i *)(stage + o));
+            const v2i hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32((GNK_LDS v2i *)(stage + o + 8 * 256));
+            return (v4i){lo[0], lo[1], hi[0], hi[1]};
+        }
+    }
+    static __device__ __forceinline__ void load_frags(const char *As, const char *Bs, v4i (&fa)[8], v4i (&fb)[4], int wm, int wn, int lane) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = load_frag16<Cfg::B_KMAJOR>(Bs, wn * 64 + 16 * j, lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[i] = load_frag16<Cfg::A_KMAJOR>(As, wm * 128 + 16 * i, lane);
+    }
+    static __device__ __forceinline__ void mfma_stage(v4i (&acc)[8][4], const v4i (&fa)[8], const v4i (&fb)[4]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb[j], fa[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));
+        __builtin_amdgcn_s_setprio(0);
+    }
+};
+
+// ---- fp8: 32 x 32 x 64 scaled MFMA tiles; wave tile 128 x 64 = 4 x 2 tiles
+template <class Cfg> struct PP2F8 {
     typedef typename Acc32<Cfg::OP>::type acc_t;
+    typedef acc_t acc_arr[4][2];
+    typedef v8i fa_arr[4];
+    typedef v8i fb_arr[2];
+    static __device__ __forceinline__ void zero(acc_arr &acc) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+    }
 
     // 32 bytes of one lane for the 32-row fragment starting at row / column rb of the stage image
     template <bool KMAJOR> static __device__ __forceinline__ v8i load_frag32(const char *stage, int rb, int lane) {
@@ -104,37 +171,18 @@ template <class Cfg> struct PP2 {
     // one stage of MFMAs: acc[i][j] (32 m x 32 n, held as D[n][m]) += B-frag(j) x A-frag(i)
     static __device__ __forceinline__ void mfma_stage(acc_t (&acc)[4][2], const v8i (&fa)[4], const v8i (&fb)[2]) {
         __builtin_amdgcn_s_setprio(1);
-        if constexpr (Cfg::OP == OP_I8) {
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const v4i a = kk == 0 ? __builtin_shufflevector(fa[i], fa[i], 0, 1, 2, 3) : __builtin_shufflevector(fa[i], fa[i], 4, 5, 6, 7);
-                        const v4i b = kk == 0 ? __builtin_shufflevector(fb[j], fb[j], 0, 1, 2, 3) : __builtin_shufflevector(fb[j], fb[j], 4, 5, 6, 7);
-                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b, a, acc[i][j], 0, 0, 0);
-                    }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[j], fa[i], acc[i][j], Cfg::FB, Cfg::FA, 0, 0x7f7f7f7f, 0,
-                                                                                 0x7f7f7f7f);   // E8M0 127 = 2^0
-        }
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[j], fa[i], acc[i][j], Cfg::FB, Cfg::FA, 0, 0x7f7f7f7f, 0,
+                                                                             0x7f7f7f7f);   // E8M0 127 = 2^0
         // pin the cluster to this phase (register-only ops are otherwise free to sink past the barriers)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(acc[i][j]));
         __builtin_amdgcn_s_setprio(0);
-    }
-
-    static __device__ __forceinline__ void phase_barrier() {
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
     }
 
     // ------------------------------------------------------------------ epilogue (32 x 32 tile maps)
@@ -212,13 +260,35 @@ template <class Cfg> struct PP2 {
             }
         }
     }
+    static __device__ __forceinline__ void finish(const GemmParams &p, acc_arr &acc, char *smem, int wave, int lane, int64_t mwave, int64_t nwave) {
+        const bool aligned16 = ((uintptr_t)p.C & 15) == 0;
+        const bool vec_ok = (p.N % 4 == 0) && aligned16, lds_ok = (p.N % 8 == 0) && aligned16;
+        if constexpr (Cfg::EPI == EPI_PLAIN && Cfg::OP == OP_I8) {
+            if (vec_ok) epilogue<GNK_I32, 1>(p, acc, smem, wave, lane, mwave, nwave);
+            else epilogue<GNK_I32, 2>(p, acc, smem, wave, lane, mwave, nwave);
+        } else if (p.out_dtype == GNK_BF16) {
+            if (lds_ok) epilogue<GNK_BF16, 0>(p, acc, smem, wave, lane, mwave, nwave);
+            else if (vec_ok) epilogue<GNK_BF16, 1>(p, acc, smem, wave, lane, mwave, nwave);
+            else epilogue<GNK_BF16, 2>(p, acc, smem, wave, lane, mwave, nwave);
+        } else if (p.out_dtype == GNK_F16) {
+            if (lds_ok) epilogue<GNK_F16, 0>(p, acc, smem, wave, lane, mwave, nwave);
+            else if (vec_ok) epilogue<GNK_F16, 1>(p, acc, smem, wave, lane, mwave, nwave);
+            else epilogue<GNK_F16, 2>(p, acc, smem, wave, lane, mwave, nwave);
+        } else {
+            if (vec_ok) epilogue<GNK_F32, 1>(p, acc, smem, wave, lane, mwave, nwave);
+            else epilogue<GNK_F32, 2>(p, acc, smem, wave, lane, mwave, nwave);
+        }
+    }
 };
+
+template <class Cfg, int OP> struct PP2Select;
+template <class Cfg> struct PP2Select<Cfg, OP_I8> { typedef PP2I8<Cfg> type; };
+template <class Cfg> struct PP2Select<Cfg, OP_F8> { typedef PP2F8<Cfg> type; };
 
 template <class Cfg>
 __global__ void __launch_bounds__(512) gemm_pp2_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef PP2<Cfg> K;
-    typedef typename K::acc_t acc_t;
+    typedef typename PP2Select<Cfg, Cfg::OP>::type K;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -232,14 +302,10 @@ __global__ void __launch_bounds__(512) gemm_pp2_kernel(const GemmParams p) {
     sa.init(p.A, p.lda, m0, p.M, wave, lane);
     sb.init(p.B, p.ldb, n0, p.N, wave, lane);
 
-    acc_t acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
-    v8i fa[4], fb[2];
+    typename K::acc_arr acc;
+    K::zero(acc);
+    typename K::fa_arr fa;
+    typename K::fb_arr fb;
 
     const int ns = (int)(p.K / Cfg::SK);
     char *const Abuf = smem, *const Bbuf = smem + Cfg::NST * Cfg::OPER_BYTES;
@@ -254,20 +320,20 @@ __global__ void __launch_bounds__(512) gemm_pp2_kernel(const GemmParams p) {
     else if (npro == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (npro == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    K::phase_barrier();
+    pp2_phase_barrier();
     K::load_frags(Abuf, Bbuf, fa, fb, wm, wn, lane);
     // stage 1 must have landed before the first LOAD phase reads it
     if (npro == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (npro == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    K::phase_barrier();
-    if (wm == 1) K::phase_barrier();   // stagger: group 1 runs one phase behind group 0
+    pp2_phase_barrier();
+    if (wm == 1) pp2_phase_barrier();   // stagger: group 1 runs one phase behind group 0
 
     for (int s = 0; s < ns; ++s) {
         // ---- MFMA phase
         K::mfma_stage(acc, fa, fb);
-        K::phase_barrier();
+        pp2_phase_barrier();
         // ---- LOAD phase
         if (s + 1 < ns) {
             const int b = (s + 1) & 3;
@@ -282,29 +348,13 @@ __global__ void __launch_bounds__(512) gemm_pp2_kernel(const GemmParams p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail: drain
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        K::phase_barrier();
+        pp2_phase_barrier();
     }
-    if (wm == 0) K::phase_barrier();   // pay the stagger back so barrier counts match
+    if (wm == 0) pp2_phase_barrier();   // pay the stagger back so barrier counts match
 
     // all LDS stage reads retired at the last barrier; each wave stages its result through its own LDS slice
     const int64_t mwave = m0 + wm * 128, nwave = n0 + wn * 64;
-    const bool aligned16 = ((uintptr_t)p.C & 15) == 0;
-    const bool vec_ok = (p.N % 4 == 0) && aligned16, lds_ok = (p.N % 8 == 0) && aligned16;
-    if constexpr (Cfg::EPI == EPI_PLAIN && Cfg::OP == OP_I8) {
-        if (vec_ok) K::template epilogue<GNK_I32, 1>(p, acc, smem, wave, lane, mwave, nwave);
-        else K::template epilogue<GNK_I32, 2>(p, acc, smem, wave, lane, mwave, nwave);
-    } else if (p.out_dtype == GNK_BF16) {
-        if (lds_ok) K::template epilogue<GNK_BF16, 0>(p, acc, smem, wave, lane, mwave, nwave);
-        else if (vec_ok) K::template epilogue<GNK_BF16, 1>(p, acc, smem, wave, lane, mwave, nwave);
-        else K::template epilogue<GNK_BF16, 2>(p, acc, smem, wave, lane, mwave, nwave);
-    } else if (p.out_dtype == GNK_F16) {
-        if (lds_ok) K::template epilogue<GNK_F16, 0>(p, acc, smem, wave, lane, mwave, nwave);
-        else if (vec_ok) K::template epilogue<GNK_F16, 1>(p, acc, smem, wave, lane, mwave, nwave);
-        else K::template epilogue<GNK_F16, 2>(p, acc, smem, wave, lane, mwave, nwave);
-    } else {
-        if (vec_ok) K::template epilogue<GNK_F32, 1>(p, acc, smem, wave, lane, mwave, nwave);
-        else K::template epilogue<GNK_F32, 2>(p, acc, smem, wave, lane, mwave, nwave);
-    }
+    K::finish(p, acc, smem, wave, lane, mwave, nwave);
 }
 
 template <class Cfg> int launch_pp2(const GemmParams &p0, hipStream_t st) {

@@ -61,30 +61,40 @@ template <int L> GNK_HD int gnk_mnmaj_frag_offset(int rb, int ks, int lane) {
 }
 
 // =============================================================================================
-// 64-k stage images of the 4-stage kernel (gnk_gemm_pp2.h): one stage of an operand is 256 x 64 bytes
-// and feeds 32-row MFMA tiles (v_mfma_i32_32x32x32_i8 / v_mfma_scale_f32_32x32x64_f8f6f4).
-// MFMA slot convention (both operands, so the dot product is k-permutation safe): lane l serves tile row
-// (l & 31) and k-half h = l >> 5; its 32 bytes are [ k = 16h .. 16h+15 | k = 32+16h .. 32+16h+15 ],
-// i.e. 16-byte chunks h and 2+h of the row.  int8 issues two K=32 MFMAs (one per 16-byte half),
-// fp8 one K=64 MFMA on all 32 bytes.
+// 64-k stage images of the 4-stage kernel (gnk_gemm_pp2.h): one stage of an operand is 256 x 64 bytes.
+// Two MFMA slot conventions read the same images (both operands use the same one, so the dot product is
+// k-permutation safe):
+//  * fp8, 32-row tiles (v_mfma_scale_f32_32x32x64_f8f6f4): lane l serves tile row (l & 31) and k-half
+//    h = l >> 5; its 32 bytes are [ k = 16h .. 16h+15 | k = 32+16h .. 32+16h+15 ] (chunks h and 2+h);
+//  * int8, 16-row tiles (v_mfma_i32_16x16x64_i8): lane l serves tile row (l & 15), k = 16 (l >> 4) .. +15.
 //
-//  * K-major stage  [256 rows][64 B]: chunk c (0..3) of row r at slot c ^ ((r >> 2) & 3).
-//  * MN-major stage [64 k][256 B]:    chunk c (0..15) of k-row k at slot c ^ ((k & 7) << 1).
-GNK_HD int gnk_k64_offset(int r, int c) { return r * 64 + ((c ^ ((r >> 2) & 3)) << 4); }
+//  * K-major stage  [256 rows][64 B]: chunk c (0..3) of row r at slot c ^ P[(r >> 2) & 3], P = {0, 2, 3, 1}
+//    (the permutation keeps ds_read_b128's lane groups {0-3,12-15,20-27}... conflict free for BOTH conventions).
+//  * MN-major stage [64 k][256 B]:    chunk c (0..15) of k-row k at slot c ^ (((k & 7) << 1) | ((k >> 4) & 1)).
+GNK_HD int gnk_k64_swz(int r) { return (0x78 >> (2 * ((r >> 2) & 3))) & 3; }
+GNK_HD int gnk_k64_offset(int r, int c) { return r * 64 + ((c ^ gnk_k64_swz(r)) << 4); }
 GNK_HD void gnk_k64_stage_src(int p, int &r, int &c) {
     r = p >> 2;
-    c = (p & 3) ^ ((r >> 2) & 3);
+    c = (p & 3) ^ gnk_k64_swz(r);
 }
-// ds_read_b128 #half (0, 1) of the fragment whose first row is rb
+// 32-row tiles: ds_read_b128 #half (0, 1) of the fragment whose first row is rb
 GNK_HD int gnk_k64_frag_offset(int rb, int half, int lane) { return gnk_k64_offset(rb + (lane & 31), 2 * half + (lane >> 5)); }
+// 16-row tiles: the one ds_read_b128 of the fragment whose first row is rb
+GNK_HD int gnk_k64_frag16_offset(int rb, int lane) { return gnk_k64_offset(rb + (lane & 15), lane >> 4); }
 
-GNK_HD int gnk_mn64_offset(int k, int c) { return k * 256 + ((c ^ ((k & 7) << 1)) << 4); }
+GNK_HD int gnk_mn64_swz(int k) { return ((k & 7) << 1) | ((k >> 4) & 1); }
+GNK_HD int gnk_mn64_offset(int k, int c) { return k * 256 + ((c ^ gnk_mn64_swz(k)) << 4); }
 GNK_HD void gnk_mn64_stage_src(int p, int &k, int &c) {
     k = p >> 4;
-    c = (p & 15) ^ ((k & 7) << 1);
+    c = (p & 15) ^ gnk_mn64_swz(k);
 }
-// ds_read_b64_tr_b8 #(half, t): k rows 32*half + 16h + 8t .. +7 of columns rb + 16*((l>>4)&1) .. +15
+// 32-column tiles: ds_read_b64_tr_b8 #(half, t): k rows 32*half + 16h + 8t .. +7 of columns rb + 16*((l>>4)&1) .. +15
 GNK_HD int gnk_mn64_frag_offset(int rb, int half, int t, int lane) {
     const int h = lane >> 5, blk = (lane >> 4) & 1, q = (lane & 15) >> 1, hb = lane & 1;
     return gnk_mn64_offset(32 * half + 16 * h + 8 * t + q, (rb >> 4) + blk) + 8 * hb;
+}
+// 16-column tiles: ds_read_b64_tr_b8 #t (0, 1): k rows 16 (l >> 4) + 8t .. +7 of columns rb .. rb+15
+GNK_HD int gnk_mn64_frag16_offset(int rb, int t, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 1, hb = lane & 1;
+    return gnk_mn64_offset(16 * g + 8 * t + q, rb >> 4) + 8 * hb;
 }

@@ -119,6 +119,62 @@ void sim_k64() {
         }
 }
 
+void sim_k64_frag16() {
+    const int ROWS = 256;
+    std::vector<Elem> lds(ROWS * 64, Elem{-1, -1});
+    for (int p = 0; p < ROWS * 4; ++p) {
+        int r, c;
+        gnk_k64_stage_src(p, r, c);
+        for (int b = 0; b < 16; ++b) lds[p * 16 + b] = Elem{r, 16 * c + b};
+    }
+    for (int rb = 0; rb < ROWS; rb += 16) {
+        int off[64];
+        for (int lane = 0; lane < 64; ++lane) {
+            off[lane] = gnk_k64_frag16_offset(rb, lane);
+            CHECK(off[lane] - gnk_k64_frag16_offset(0, lane) == rb * 64, "k64/16: row block %d is not a constant byte offset", rb);
+            for (int b = 0; b < 16; ++b) {
+                Elem e = lds[off[lane] + b];
+                CHECK(e.row == rb + (lane & 15) && e.k == 16 * (lane >> 4) + b, "k64/16 rb=%d lane=%d byte=%d: got (%d,%d)", rb, lane, b, e.row, e.k);
+            }
+        }
+        for (int g = 0; g < 4; ++g) {
+            std::set<int> slots;
+            for (int i = 0; i < 16; ++i) slots.insert((off[B128_GROUPS[g][i]] / 16) % 16);
+            CHECK(slots.size() == 16, "k64/16 rb=%d: b128 group %d has a bank conflict (%zu slots)", rb, g, slots.size());
+        }
+    }
+}
+
+void sim_mn64_frag16() {
+    std::vector<Elem> lds(64 * 256, Elem{-1, -1});
+    for (int p = 0; p < 64 * 16; ++p) {
+        int k, c;
+        gnk_mn64_stage_src(p, k, c);
+        for (int b = 0; b < 16; ++b) lds[p * 16 + b] = Elem{16 * c + b, k};
+    }
+    for (int rb = 0; rb < 256; rb += 16)
+        for (int t = 0; t < 2; ++t) {
+            int addr[64];
+            for (int lane = 0; lane < 64; ++lane) {
+                addr[lane] = gnk_mn64_frag16_offset(rb, t, lane);
+                CHECK(addr[lane] == gnk_mn64_frag16_offset(rb, 0, lane) + t * 8 * 256, "mn64/16: second read is not +8 k-rows");
+            }
+            for (int lane = 0; lane < 64; ++lane) {
+                const int grp = lane & ~15, i = lane & 15;
+                for (int b = 0; b < 8; ++b) {
+                    Elem e = lds[addr[grp + 2 * b + (i >> 3)] + (i & 7)];
+                    const int want_n = rb + i, want_k = 16 * (lane >> 4) + 8 * t + b;
+                    CHECK(e.row == want_n && e.k == want_k, "mn64/16 rb=%d t=%d lane=%d byte=%d: got (n=%d,k=%d) want (%d,%d)", rb, t, lane, b, e.row, e.k, want_n, want_k);
+                }
+            }
+            for (int h = 0; h < 2; ++h) {
+                std::set<int> slots;
+                for (int i = 0; i < 32; ++i) slots.insert((addr[32 * h + i] / 8) % 32);
+                CHECK(slots.size() == 32, "mn64/16 rb=%d t=%d: b64 half %d has a bank conflict (%zu slots)", rb, t, h, slots.size());
+            }
+        }
+}
+
 void sim_mn64() {
     std::vector<Elem> lds(64 * 256, Elem{-1, -1});
     std::set<int> seen;
@@ -133,7 +189,10 @@ void sim_mn64() {
         for (int half = 0; half < 2; ++half)
             for (int t = 0; t < 2; ++t) {
                 int addr[64];
-                for (int lane = 0; lane < 64; ++lane) addr[lane] = gnk_mn64_frag_offset(rb, half, t, lane);
+                for (int lane = 0; lane < 64; ++lane) {
+                    addr[lane] = gnk_mn64_frag_offset(rb, half, t, lane);
+                    CHECK(addr[lane] == gnk_mn64_frag_offset(rb, 0, 0, lane) + (32 * half + 8 * t) * 256, "mn64: read (%d,%d) is not a constant offset from read (0,0)", half, t);
+                }
                 for (int lane = 0; lane < 64; ++lane) {
                     const int grp = lane & ~15, i = lane & 15;
                     for (int b = 0; b < 8; ++b) {
@@ -153,6 +212,8 @@ void sim_mn64() {
 int main() {
     sim_k64();
     sim_mn64();
+    sim_k64_frag16();
+    sim_mn64_frag16();
     sim_kmajor<128>();
     sim_kmajor<256>();
     sim_mnmajor<128>();

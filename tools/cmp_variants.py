@@ -9,8 +9,6 @@ import torch
 import gn_kernels
 from gn_kernels import _cabi
 
-L = _cabi.load()
-
 
 def timeit(fn, iters=30):
     for _ in range(5):
@@ -28,23 +26,29 @@ def lay(x, cm):
     return x.T.contiguous().T if cm else x.contiguous()
 
 
-S = 4096
-rs = torch.randn(S, 1, device="cuda").div(128).bfloat16()
-cs = torch.randn(1, S, device="cuda").div(128).bfloat16()
-VARS = {"pp2": 0, "pp8": 4, "128": 1}
-for K in (256, 1024, 4096, 8192):
-    for name, (acm, bcm) in {"nt": (False, True), "nn": (False, False), "tn": (True, False)}.items():
-        A = lay(torch.randint(-128, 127, (S, K), dtype=torch.int8, device="cuda"), acm)
-        B = lay(torch.randint(-128, 127, (K, S), dtype=torch.int8, device="cuda"), bcm)
-        A8 = lay(torch.randn(S, K, device="cuda").to(torch.float8_e4m3fn), acm)
-        B8 = lay(torch.randn(K, S, device="cuda").to(torch.float8_e4m3fn), bcm)
-        out = []
-        for vn, v in VARS.items():
-            L.gnk_set_gemm_variant(v)
-            t = timeit(lambda: gn_kernels.scaled_mm(A, B, rs, cs))
-            out.append(f"i8 {vn} {t:7.1f}us {2*S*S*K/t/1e6:6.0f}T")
-            if vn != "pp8":
-                t = timeit(lambda: gn_kernels.scaled_mm(A8, B8, rs, cs))
-                out.append(f"f8 {vn} {t:7.1f}us {2*S*S*K/t/1e6:6.0f}T")
-        L.gnk_set_gemm_variant(-1)
-        print(f"K={K:5d} {name}: " + " | ".join(out), flush=True)
+def main(ks=(256, 1024, 4096, 8192), variants=None):
+    L = _cabi.load()
+    S = 4096
+    rs = torch.randn(S, 1, device="cuda").div(128).bfloat16()
+    cs = torch.randn(1, S, device="cuda").div(128).bfloat16()
+    variants = variants or {"pp2": 0, "pp8": 4, "128": 1}
+    for K in ks:
+        for name, (acm, bcm) in {"nt": (False, True), "nn": (False, False), "tn": (True, False)}.items():
+            A = lay(torch.randint(-128, 127, (S, K), dtype=torch.int8, device="cuda"), acm)
+            B = lay(torch.randint(-128, 127, (K, S), dtype=torch.int8, device="cuda"), bcm)
+            A8 = lay(torch.randn(S, K, device="cuda").to(torch.float8_e4m3fn), acm)
+            B8 = lay(torch.randn(K, S, device="cuda").to(torch.float8_e4m3fn), bcm)
+            out = []
+            for vn, v in variants.items():
+                L.gnk_set_gemm_variant(v)
+                t = timeit(lambda: gn_kernels.scaled_mm(A, B, rs, cs))
+                out.append(f"i8 {vn} {t:7.1f}us {2*S*S*K/t/1e6:6.0f}T")
+                if vn != "pp8":
+                    t = timeit(lambda: gn_kernels.scaled_mm(A8, B8, rs, cs))
+                    out.append(f"f8 {vn} {t:7.1f}us {2*S*S*K/t/1e6:6.0f}T")
+            L.gnk_set_gemm_variant(-1)
+            print(f"K={K:5d} {name}: " + " | ".join(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
