@@ -176,7 +176,8 @@ def main():
         achieved = 2 * S ** 3 / (avg_ms * 1e-3) * 1e-12
         out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_DENSE_8BIT_TOPS, "unit": "TFLOP/s",
                            "frac": round(achieved / PEAK_DENSE_8BIT_TOPS, 4), "traffic": None,
-                           "kernel": "gemm_kernel<256x256, int8, A K-major, B K-major, row/col epilogue>",
+                           "kernel": "gemm_pp_kernel<256x256 tile, 8 waves, 8-phase ping-pong, int8 v_mfma_i32_16x16x64_i8, A K-major, B K-major, row/col epilogue>",
+                           "traffic_note": "HBM-side bytes per launch from rocprofv3 PMC passes: see profiles/ (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
                            "avg_launch_us": round(avg_ms * 1e3, 2), "median_launch_us": round(med_ms * 1e3, 2),
                            "algorithmic_ops_per_launch": 2 * S ** 3}
         if not args.no_detail:
