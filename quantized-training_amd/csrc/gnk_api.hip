@@ -131,7 +131,13 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
                              lb.ld * 256 < (1LL << 31) && ((c.M + 127) / 128) * ((c.N + 127) / 128) < (1LL << 31);
     // 4-stage 256^2 kernel: 64-k stages, no tile-scaled epilogue; the two-buffer kernels step 128 k
     const bool ok_pp2 = fast_layout && c.K >= 64 && c.K % 64 == 0 && c.epi != EPI_TILE;
-    const bool ok_128 = fast_layout && c.K >= GNK_BK && c.K % GNK_BK == 0 && (c.epi != EPI_TILE || c.QK == GNK_BK);
+    // tile-scaled fast path: one scale block per 128-k step, and scale offsets that fit 32-bit indices
+    bool tile_ok = true;
+    if (c.epi == EPI_TILE) {
+        const int64_t amax = ((c.M - 1) / c.QM) * c.ssam + (c.K / c.QK) * c.ssak, bmax = (c.K / c.QK) * c.ssbk + ((c.N - 1) / c.QN) * c.ssbn;
+        tile_ok = c.QK == GNK_BK && c.QN % 4 == 0 && c.N % 4 == 0 && c.ssam >= 0 && c.ssak >= 0 && c.ssbk >= 0 && c.ssbn >= 0 && amax < (1LL << 31) && bmax < (1LL << 31);
+    }
+    const bool ok_128 = fast_layout && c.K >= GNK_BK && c.K % GNK_BK == 0 && tile_ok;
     if ((variant == GNK_VARIANT_256_SIMPLE || variant == GNK_VARIANT_256_PP8) && (op != OP_I8 || c.epi == EPI_TILE)) variant = GNK_VARIANT_256;
     if (variant == GNK_VARIANT_256 && c.epi == EPI_TILE) variant = GNK_VARIANT_128;
     if (variant < 0 || variant > GNK_VARIANT_LAST) {

@@ -62,6 +62,17 @@ template <int DT> __device__ __forceinline__ float gnk_load_scalar(const void *p
     else return ((const float *)p)[i];
 }
 
+// raw bits now, float later: lets a load stay in flight until its value is needed
+template <int DT> __device__ __forceinline__ unsigned gnk_load_raw(const void *p, int64_t i) {
+    if constexpr (DT == GNK_F32) return ((const unsigned *)p)[i];
+    else return ((const unsigned short *)p)[i];
+}
+template <int DT> __device__ __forceinline__ float gnk_raw_to_f32(unsigned raw) {
+    if constexpr (DT == GNK_BF16) return gnk_bf16_to_f32((unsigned short)raw);
+    else if constexpr (DT == GNK_F16) return gnk_f16_to_f32((unsigned short)raw);
+    else return __uint_as_float(raw);
+}
+
 __device__ __forceinline__ float gnk_load_scalar_rt(const void *p, int dt, int64_t i) {
     if (dt == GNK_BF16) return gnk_bf16_to_f32(((const unsigned short *)p)[i]);
     if (dt == GNK_F16) return gnk_f16_to_f32(((const unsigned short *)p)[i]);

@@ -144,8 +144,9 @@ template <int OP> struct AccT;
 template <> struct AccT<OP_I8> { typedef v4i type; };
 template <> struct AccT<OP_F8> { typedef v4f type; };
 
-// one K-step (128 k) of MFMAs for this wave
-template <class Cfg>
+// one K-step (128 k) of MFMAs for this wave.  FRESH: start from C = 0 (inline constant: the tile-scaled
+// kernel rescales every K-block's partial sum separately and needs no accumulator re-zeroing).
+template <class Cfg, bool FRESH = false>
 __device__ __forceinline__ void compute_step(const char *As, const char *Bs, typename AccT<Cfg::OP>::type (&acc)[Cfg::MT][Cfg::NTL],
                                              int wm, int wn, int lane) {
     constexpr int MT = Cfg::MT, NTL = Cfg::NTL;
@@ -161,7 +162,7 @@ __device__ __forceinline__ void compute_step(const char *As, const char *Bs, typ
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NTL; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb[j], fa[i], (FRESH && ks == 0) ? (v4i){0, 0, 0, 0} : acc[i][j], 0, 0, 0);
         }
     } else {
         // fp8: one 16x16x128 MFMA per tile pair; lane slot (g, byte) <-> k = 64*(byte/16) + 16g + byte%16
@@ -180,8 +181,8 @@ __device__ __forceinline__ void compute_step(const char *As, const char *Bs, typ
             v8i fa = (v8i){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
             for (int j = 0; j < NTL; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[j], fa, acc[i][j], Cfg::FB, Cfg::FA, 0, 0x7f7f7f7f, 0,
-                                                                             0x7f7f7f7f);   // E8M0 127 = 2^0
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[j], fa, FRESH ? (v4f){0.f, 0.f, 0.f, 0.f} : acc[i][j], Cfg::FB, Cfg::FA, 0,
+                                                                             0x7f7f7f7f, 0, 0x7f7f7f7f);   // E8M0 127 = 2^0
         }
     }
 }
@@ -370,6 +371,65 @@ __device__ __forceinline__ void run_epilogue(const GemmParams &p, typename AccT<
     }
 }
 
+// ------------------------------------------------------------------------------ tile-scale indexing
+// Element offsets of this lane's scale blocks, computed ONCE (divisions by QM / QN per K-step, and dtype
+// branches between dependent loads, made the first tile-scaled kernel 10x slower than the row-scaled one).
+// The fast path requires QN % 4 == 0 and N % 4 == 0 (a lane's 4 consecutive n share one block) and scale
+// offsets < 2^31 (host-checked).  Scales are fetched as RAW bits one K-step ahead and converted at use,
+// so their latency hides under a whole step of MFMAs instead of stalling the step that needs them.
+template <class Cfg> struct TileScaleIdx {
+    static constexpr int MT = Cfg::EPI == EPI_TILE ? Cfg::MT : 1, NTL = Cfg::EPI == EPI_TILE ? Cfg::NTL : 1;
+    int aoff[MT];
+    int boff[NTL];
+    int astep, bstep;
+    __device__ __forceinline__ void init(const GemmParams &p, int64_t mrow, int64_t ncol) {
+        const unsigned qm = (unsigned)p.QM, qn = (unsigned)p.QN;   // M, N < 2^31 on this path: 32-bit division
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            int64_t m = mrow + 16 * i;
+            m = m < p.M ? m : p.M - 1;
+            aoff[i] = (int)(((unsigned)m / qm) * (unsigned)p.ssam);
+        }
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            int64_t n = ncol + 16 * j;
+            n = n < p.N ? n : p.N - 1;
+            boff[j] = (int)(((unsigned)n / qn) * (unsigned)p.ssbn);
+        }
+        astep = (int)p.ssak;
+        bstep = (int)p.ssbk;
+    }
+    template <int SDT> __device__ __forceinline__ void load_raw_t(const GemmParams &p, int t, unsigned (&ra)[MT], unsigned (&rb)[NTL]) const {
+        const int at = t * astep, bt = t * bstep;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) ra[i] = gnk_load_raw<SDT>(p.s0, aoff[i] + at);
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) rb[j] = gnk_load_raw<SDT>(p.s1, boff[j] + bt);
+    }
+    __device__ __forceinline__ void load_raw(const GemmParams &p, int t, unsigned (&ra)[MT], unsigned (&rb)[NTL]) const {
+        if (p.scale_dtype == GNK_F32) load_raw_t<GNK_F32>(p, t, ra, rb);
+        else load_raw_t<GNK_BF16>(p, t, ra, rb);   // bf16 and fp16 are both 2-byte loads
+    }
+    static __device__ __forceinline__ void convert(const GemmParams &p, const unsigned (&ra)[MT], const unsigned (&rb)[NTL], float (&sav)[MT], float (&sbv)[NTL]) {
+        if (p.scale_dtype == GNK_BF16) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) sav[i] = gnk_raw_to_f32<GNK_BF16>(ra[i]);
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) sbv[j] = gnk_raw_to_f32<GNK_BF16>(rb[j]);
+        } else if (p.scale_dtype == GNK_F16) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) sav[i] = gnk_raw_to_f32<GNK_F16>(ra[i]);
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) sbv[j] = gnk_raw_to_f32<GNK_F16>(rb[j]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) sav[i] = gnk_raw_to_f32<GNK_F32>(ra[i]);
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) sbv[j] = gnk_raw_to_f32<GNK_F32>(rb[j]);
+        }
+    }
+};
+
 // ------------------------------------------------------------------------------ the kernel
 template <class Cfg>
 __global__ void __launch_bounds__(Cfg::NT) gemm_kernel(const GemmParams p) {
@@ -413,6 +473,13 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_kernel(const GemmParams p) {
             for (int j = 0; j < NTL; ++j) accf[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
     }
 
+    TileScaleIdx<Cfg> ts;
+    unsigned raw_a[Cfg::EPI == EPI_TILE ? MT : 1], raw_b[Cfg::EPI == EPI_TILE ? NTL : 1];
+    if constexpr (Cfg::EPI == EPI_TILE) {
+        ts.init(p, mrow, ncol);
+        if (p.K >= GNK_BK) ts.load_raw(p, 0, raw_a, raw_b);
+    }
+
     const int nk = (int)(p.K / GNK_BK);
     sa.issue(As0, wave);
     sb.issue(Bs0, wave);
@@ -420,25 +487,13 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_kernel(const GemmParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
-        // tile-scaled: fetch this K-block's scales BEFORE the next stage is issued, so that the
-        // wait on them cannot drain the LDS-DMA loads that should stay in flight under the MFMAs
+        // tile-scaled: this K-block's scales arrived with the vmcnt(0) above; fetch the next block's BEFORE
+        // the next stage is issued (they are waited for together at the top of the next step)
         float sav[Cfg::EPI == EPI_TILE ? MT : 1];
-        float sbv[Cfg::EPI == EPI_TILE ? NTL : 1][4];
+        float sbv[Cfg::EPI == EPI_TILE ? NTL : 1];
         if constexpr (Cfg::EPI == EPI_TILE) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                int64_t m = mrow + 16 * i;
-                m = m < p.M ? m : p.M - 1;
-                sav[i] = gnk_load_scalar_rt(p.s0, p.scale_dtype, (m / p.QM) * p.ssam + t * p.ssak);
-            }
-#pragma unroll
-            for (int j = 0; j < NTL; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int64_t n = ncol + 16 * j + r;
-                    n = n < p.N ? n : p.N - 1;
-                    sbv[j][r] = gnk_load_scalar_rt(p.s1, p.scale_dtype, t * p.ssbk + (n / p.QN) * p.ssbn);
-                }
+            TileScaleIdx<Cfg>::convert(p, raw_a, raw_b, sav, sbv);
+            if (t + 1 < nk) ts.load_raw(p, t + 1, raw_a, raw_b);
         }
 
         const int cur = t & 1;
@@ -446,7 +501,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_kernel(const GemmParams p) {
             sa.issue(As0 + (cur ^ 1) * Cfg::A_BYTES, wave);
             sb.issue(Bs0 + (cur ^ 1) * Cfg::B_BYTES, wave);
         }
-        compute_step<Cfg>(As0 + cur * Cfg::A_BYTES, Bs0 + cur * Cfg::B_BYTES, acc, wm, wn, lane);
+        compute_step<Cfg, Cfg::EPI == EPI_TILE>(As0 + cur * Cfg::A_BYTES, Bs0 + cur * Cfg::B_BYTES, acc, wm, wn, lane);
 
         if constexpr (Cfg::EPI == EPI_TILE) {
             // acc_f32 += (f32(partial) * sA[m/QM, t]) * sB[t, n/QN]   (triton_mm.py:327-331), no FMA
@@ -460,10 +515,9 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_kernel(const GemmParams p) {
                         if constexpr (Cfg::OP == OP_I8) part = (float)acc[i][j][r];
                         else part = acc[i][j][r];
                         float tmp = __fmul_rn(part, sav[i]);
-                        tmp = __fmul_rn(tmp, sbv[j][r]);
+                        tmp = __fmul_rn(tmp, sbv[j]);
                         accf[i][j][r] = __fadd_rn(accf[i][j][r], tmp);
                     }
-                    acc[i][j] = (acc_t){0, 0, 0, 0};
                 }
         }
     }
