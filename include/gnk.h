@@ -128,7 +128,8 @@ int gnk_set_gemm_variant(int variant);
 
 /*
  * Timing-ablation hook (no reference counterpart; results are WRONG while flags != 0): bit 0 drops the
- * main loop's LDS-DMA loads, bit 1 the MFMAs, bit 2 the LDS fragment reads of the 256 x 256 kernel.
+ * main loop's LDS-DMA loads, bit 1 the MFMAs, bit 2 the LDS fragment reads of the 8-phase 256 x 256 kernel
+ * (variant 4; the other kernels ignore the flags).
  * Used by tools/ablate.py to attribute kernel time.  Returns the previous flags.
  */
 int gnk_set_debug_flags(int flags);
