@@ -195,13 +195,18 @@ def main():
             # quantize pass: algorithmic bytes = 3*R*C + 2*R (read bf16 once, write int8 + bf16 scales)
             from subclasses import quantize_int8
 
-            x = torch.randn(S, S, device=dev).bfloat16()
+            # event-timed through the op (Python dispatch + ctypes ~ 17-20 us per call is inside the number: at
+            # 4096^2 the kernels themselves take 12 us row-wise / 19 us column-wise, profiles/*kernel_stats*)
             q = {}
-            for name, dim in (("rowwise (reduce contiguous dim)", 1), ("colwise (reduce strided dim)", 0)):
-                avg, _ = time_kernel(lambda dim=dim: quantize_int8(x, dim=dim), iters=30)
-                gbs = (3 * S * S + 2 * S) / (avg * 1e-3) * 1e-9
-                q[name] = {"GB/s": round(gbs, 1), "frac_of_8TBs": round(gbs / PEAK_HBM_GBS, 4), "us": round(avg * 1e3, 2)}
-            out["detail_quantize_4096x4096_bf16"] = q
+            for R, C in ((S, S), (4 * S, 2 * S)):
+                x = torch.randn(R, C, device=dev).bfloat16()
+                for name, dim in (("rowwise (reduce contiguous dim)", 1), ("colwise (reduce strided dim)", 0)):
+                    avg, _ = time_kernel(lambda dim=dim: quantize_int8(x, dim=dim), iters=30)
+                    nbytes = 3 * R * C + 2 * (R if dim == 1 else C)
+                    gbs = nbytes / (avg * 1e-3) * 1e-9
+                    q[f"{R}x{C} {name}"] = {"GB/s": round(gbs, 1), "frac_of_8TBs": round(gbs / PEAK_HBM_GBS, 4), "us": round(avg * 1e3, 2)}
+                del x
+            out["detail_quantize_bf16"] = q
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -25,6 +25,8 @@ int gnk_check_launch(const char *what) {
 
 static int g_cus[64];
 
+int gnk_debug_flags_get(void) { return g_debug_flags; }
+
 int gnk_num_cus(void) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;

@@ -20,6 +20,7 @@ typedef unsigned short us8 __attribute__((ext_vector_type(8)));
 // ---------------------------------------------------------------- host-side error plumbing
 int gnk_fail(int code, const char *fmt, ...);   // records a thread-local message, returns code
 int gnk_check_launch(const char *what);        // hipGetLastError -> GNK_ERR_LAUNCH
+int gnk_debug_flags_get(void);                  // timing-experiment flags of the calling thread (gnk_set_debug_flags)
 int gnk_num_cus(void);                         // CU count of the current device (cached)
 
 static inline bool gnk_is_float_dtype(int d) { return d == GNK_BF16 || d == GNK_F16 || d == GNK_F32; }
@@ -120,3 +121,27 @@ __device__ __forceinline__ int gnk_quant_one(float x, float div, unsigned long l
     v = fminf(fmaxf(v, -128.0f), 127.0f);
     return (int)v;
 }
+
+// Division by a divisor that many elements share.  A true fp32 division is ~10 VALU instructions
+// (v_div_scale x2, v_rcp, 5 FMAs, v_div_fmas, v_div_fixup), half of which depend on the divisor only; at 3 B of
+// HBM traffic per element that made the quantize kernels VALU-bound (21 VALU instructions per element).
+// GnkDivisor keeps the refined reciprocal; quot() is the remaining per-element part of the SAME sequence the
+// compiler emits for `x / d` (q0 = x*r; two residual-correction FMAs pairs), minus the power-of-two pre-scaling
+// and the special-value fix-up, which cannot change the result while d is in [2^-60, 2^60] and x is finite with
+// |x / d| < 2^24 (ok() says whether d qualifies; callers fall back to `/` otherwise -- inf / NaN / tiny scales).
+struct GnkDivisor {
+    float d, r;
+    __device__ __forceinline__ void set(float div) {
+        d = div;
+        const float r0 = __builtin_amdgcn_rcpf(div);
+        r = __builtin_fmaf(__builtin_fmaf(-div, r0, 1.0f), r0, r0);
+    }
+    __device__ __forceinline__ bool ok() const { return d >= 0x1p-60f && d <= 0x1p60f; }   // false for NaN
+    __device__ __forceinline__ float quot(float x) const {
+        const float q0 = x * r;
+        const float q1 = __builtin_fmaf(__builtin_fmaf(-d, q0, x), r, q0);
+        return __builtin_fmaf(__builtin_fmaf(-d, q1, x), r, q1);
+    }
+};
+
+__device__ __forceinline__ int gnk_rne_clip_i8(float v) { return (int)fminf(fmaxf(rintf(v), -128.0f), 127.0f); }

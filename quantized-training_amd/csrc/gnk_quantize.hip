@@ -54,6 +54,36 @@ __device__ __forceinline__ unsigned pack4_i8(int a, int b, int c, int d) {
 // Requirements (checked on the host): sxc == 1, sqc == 1, C % VEC == 0, row starts 16-B aligned
 // for x and VEC-byte aligned for q, C <= 64 * VEC * NCH.
 // ------------------------------------------------------------------------------------------
+// FAST: the row's divisor passed GnkDivisor::ok() (wave-uniform), so the shared-reciprocal division applies.
+template <int DT, bool SR, int VEC>
+__device__ __forceinline__ void quant_chunk(const v4i &raw, const GnkDivisor &dv, bool fast, int8_t *qdst, unsigned long long seed,
+                                            unsigned long long offset, unsigned long long idx0) {
+    float f[VEC];
+    unpack16<DT>(raw, f);
+    int qi[VEC];
+    if constexpr (SR) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) qi[j] = gnk_quant_one<true>(f[j], dv.d, seed, offset, idx0 + j);
+    } else {
+        if (fast) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) qi[j] = gnk_rne_clip_i8(dv.quot(f[j]));
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) qi[j] = gnk_rne_clip_i8(f[j] / dv.d);
+        }
+    }
+    if constexpr (VEC == 8) {
+        v2i o = {(int)pack4_i8(qi[0], qi[1], qi[2], qi[3]), (int)pack4_i8(qi[4], qi[5], qi[6], qi[7])};
+        *(v2i *)qdst = o;
+    } else {
+        *(unsigned *)qdst = pack4_i8(qi[0], qi[1], qi[2], qi[3]);
+    }
+}
+
+// Each wave walks rows wave_id, wave_id + nwaves, ... and loads row i+1 while it reduces, quantizes and stores
+// row i: with one row per wave every wave of the chip is in the same phase at the same time (all loading, then
+// all computing, then all storing) and HBM idles two thirds of the time.
 template <int DT, int NCH, bool SR>
 __global__ void __launch_bounds__(256)
 quant_rowwise_kernel(const char *__restrict__ x, int8_t *__restrict__ q, void *__restrict__ scale,
@@ -61,48 +91,51 @@ quant_rowwise_kernel(const char *__restrict__ x, int8_t *__restrict__ q, void *_
                      unsigned long long seed, unsigned long long offset) {
     constexpr int VEC = ElemTraits<DT>::VEC;
     const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;                                      // wave-uniform
     const int nchunks = (int)(C / VEC);
-    const char *xrow = x + r * sxr_bytes;
 
-    v4i raw[NCH];
+    v4i raw[NCH], nxt[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int ch = i * 64 + lane;
-        raw[i] = (v4i){0, 0, 0, 0};
-        if (ch < nchunks) raw[i] = *(const v4i *)(xrow + (int64_t)ch * 16);
+        nxt[i] = (v4i){0, 0, 0, 0};
+        if (ch < nchunks) nxt[i] = *(const v4i *)(x + r * sxr_bytes + (int64_t)ch * 16);
     }
-    float amax = 0.0f;
+    for (; r < R; r += nwaves) {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        float f[VEC];
-        unpack16<DT>(raw[i], f);
+        for (int i = 0; i < NCH; ++i) raw[i] = nxt[i];
+        const int64_t rn = r + nwaves;
+        if (rn < R) {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) amax = fmaxf(amax, fabsf(f[j]));
-    }
-    amax = wave_max(amax);
-    const float s = amax / 127.0f;
-    const float div = fmaxf(s, eps);
-    if (lane == 0) gnk_store_scalar_rt(scale, DT, r, s);
-
-    int8_t *qrow = q + r * sqr;
+            for (int i = 0; i < NCH; ++i) {
+                const int ch = i * 64 + lane;
+                if (ch < nchunks) nxt[i] = *(const v4i *)(x + rn * sxr_bytes + (int64_t)ch * 16);
+            }
+        }
+        float amax = 0.0f;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int ch = i * 64 + lane;
-        if (ch < nchunks) {
+        for (int i = 0; i < NCH; ++i) {
             float f[VEC];
             unpack16<DT>(raw[i], f);
-            int qi[VEC];
 #pragma unroll
-            for (int j = 0; j < VEC; ++j)
-                qi[j] = gnk_quant_one<SR>(f[j], div, seed, offset, (unsigned long long)(r * C + (int64_t)ch * VEC + j));
-            if constexpr (VEC == 8) {
-                v2i o = {(int)pack4_i8(qi[0], qi[1], qi[2], qi[3]), (int)pack4_i8(qi[4], qi[5], qi[6], qi[7])};
-                *(v2i *)(qrow + (int64_t)ch * 8) = o;
-            } else {
-                *(unsigned *)(qrow + (int64_t)ch * 4) = pack4_i8(qi[0], qi[1], qi[2], qi[3]);
-            }
+            for (int j = 0; j < VEC; ++j) amax = fmaxf(amax, fabsf(f[j]));
+        }
+        amax = wave_max(amax);
+        const float s = amax / 127.0f;
+        GnkDivisor dv;
+        dv.set(fmaxf(s, eps));
+        const bool fast = dv.ok();
+        if (lane == 0) gnk_store_scalar_rt(scale, DT, r, s);
+
+        int8_t *qrow = q + r * sqr;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = i * 64 + lane;
+            if (ch < nchunks)
+                quant_chunk<DT, SR, VEC>(raw[i], dv, fast, qrow + (int64_t)ch * VEC, seed, offset,
+                                         (unsigned long long)(r * C + (int64_t)ch * VEC));
         }
     }
 }
@@ -131,23 +164,14 @@ quant_rowwise_long_kernel(const char *__restrict__ x, int8_t *__restrict__ q, vo
     __syncthreads();
     amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     const float s = amax / 127.0f;
-    const float div = fmaxf(s, eps);
+    GnkDivisor dv;
+    dv.set(fmaxf(s, eps));
+    const bool fast = dv.ok();
     if (threadIdx.x == 0) gnk_store_scalar_rt(scale, DT, r, s);
     int8_t *qrow = q + r * sqr;
-    for (int64_t ch = threadIdx.x; ch < nchunks; ch += 256) {
-        float f[VEC];
-        unpack16<DT>(*(const v4i *)(xrow + ch * 16), f);
-        int qi[VEC];
-#pragma unroll
-        for (int j = 0; j < VEC; ++j)
-            qi[j] = gnk_quant_one<SR>(f[j], div, seed, offset, (unsigned long long)(r * C + ch * VEC + j));
-        if constexpr (VEC == 8) {
-            v2i o = {(int)pack4_i8(qi[0], qi[1], qi[2], qi[3]), (int)pack4_i8(qi[4], qi[5], qi[6], qi[7])};
-            *(v2i *)(qrow + ch * 8) = o;
-        } else {
-            *(unsigned *)(qrow + ch * 4) = pack4_i8(qi[0], qi[1], qi[2], qi[3]);
-        }
-    }
+    for (int64_t ch = threadIdx.x; ch < nchunks; ch += 256)
+        quant_chunk<DT, SR, VEC>(*(const v4i *)(xrow + ch * 16), dv, fast, qrow + ch * VEC, seed, offset,
+                                 (unsigned long long)(r * C + ch * VEC));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -169,15 +193,20 @@ col_absmax_kernel(const char *__restrict__ x, unsigned *__restrict__ amax_ws, in
 #pragma unroll
     for (int j = 0; j < VEC; ++j) m[j] = 0.0f;
     if (col0 < Q) {
-#pragma unroll 4
-        for (int i = 0; i < COL_PB / 8; ++i) {
-            const int64_t row = row0 + i * 8 + rl;
-            if (row < P) {
-                float f[VEC];
-                unpack16<DT>(*(const v4i *)(x + row * ld_bytes + col0 * (16 / VEC)), f);
+        constexpr int NIT = COL_PB / 8;
+        v4i raw[NIT];
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) m[j] = fmaxf(m[j], fabsf(f[j]));
-            }
+        for (int i = 0; i < NIT; ++i) {
+            const int64_t row = row0 + i * 8 + rl;
+            raw[i] = (v4i){0, 0, 0, 0};
+            if (row < P) raw[i] = *(const v4i *)(x + row * ld_bytes + col0 * (16 / VEC));
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            float f[VEC];
+            unpack16<DT>(raw[i], f);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) m[j] = fmaxf(m[j], fabsf(f[j]));
         }
     }
 #pragma unroll
@@ -203,23 +232,42 @@ col_quant_kernel(const char *__restrict__ x, int8_t *__restrict__ q, void *__res
     const int64_t col0 = ((int64_t)blockIdx.x * 32 + cl) * VEC;
     const int64_t row0 = (int64_t)blockIdx.y * COL_PB;
     if (col0 >= Q) return;
-    float div[VEC];
+    GnkDivisor dv[VEC];
+    bool fast = true;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         const float s = __uint_as_float(amax_ws[col0 + j]) / 127.0f;
-        div[j] = fmaxf(s, eps);
+        dv[j].set(fmaxf(s, eps));
+        fast = fast && dv[j].ok();
         if (blockIdx.y == 0 && rl == 0) gnk_store_scalar_rt(scale, DT, col0 + j, s);
     }
-#pragma unroll 4
-    for (int i = 0; i < COL_PB / 8; ++i) {
+    // all of this thread's rows are loaded before the first is used: 16 x 16 B in flight per lane
+    constexpr int NIT = COL_PB / 8;
+    v4i raw[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int64_t row = row0 + i * 8 + rl;
+        raw[i] = (v4i){0, 0, 0, 0};
+        if (row < P) raw[i] = *(const v4i *)(x + row * ld_bytes + col0 * (16 / VEC));
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
         const int64_t row = row0 + i * 8 + rl;
         if (row < P) {
             float f[VEC];
-            unpack16<DT>(*(const v4i *)(x + row * ld_bytes + col0 * (16 / VEC)), f);
+            unpack16<DT>(raw[i], f);
             int qi[VEC];
+            if constexpr (SR) {
 #pragma unroll
-            for (int j = 0; j < VEC; ++j)   // logical element (r = col, c = row) of the (Q, P) view
-                qi[j] = gnk_quant_one<SR>(f[j], div[j], seed, offset, (unsigned long long)((col0 + j) * P + row));
+                for (int j = 0; j < VEC; ++j)   // logical element (r = col, c = row) of the (Q, P) view
+                    qi[j] = gnk_quant_one<true>(f[j], dv[j].d, seed, offset, (unsigned long long)((col0 + j) * P + row));
+            } else if (fast) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) qi[j] = gnk_rne_clip_i8(dv[j].quot(f[j]));
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) qi[j] = gnk_rne_clip_i8(f[j] / dv[j].d);
+            }
             if constexpr (VEC == 8) {
                 v2i o = {(int)pack4_i8(qi[0], qi[1], qi[2], qi[3]), (int)pack4_i8(qi[4], qi[5], qi[6], qi[7])};
                 *(v2i *)(q + row * ldq + col0) = o;
@@ -262,7 +310,11 @@ int launch_rowwise(const void *x, int8_t *q, void *scale, int64_t R, int64_t C, 
     constexpr int VEC = ElemTraits<DT>::VEC;
     const int64_t sxr_bytes = sxr * (16 / VEC);
     const int64_t per_lane = (C / VEC + 63) / 64;
-    const dim3 grid((unsigned)((R + 3) / 4)), block(256);
+    // at most 8 waves per CU: each wave then pipelines R / (8 * CUs) rows
+    // one row per wave until the grid exceeds 64 blocks per CU; beyond that waves loop over rows
+    const int64_t max_blocks = (int64_t)gnk_num_cus() * 64;
+    const int64_t want = (R + 3) / 4;
+    const dim3 grid((unsigned)(want < max_blocks ? want : max_blocks)), block(256);
 #define GNK_ROW(NCH)                                                                                              \
     hipLaunchKernelGGL((quant_rowwise_kernel<DT, NCH, SR>), grid, block, 0, st, (const char *)x, q, scale, R, C,  \
                        sxr_bytes, sqr, eps, seed, offset)
