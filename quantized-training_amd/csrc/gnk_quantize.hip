@@ -178,9 +178,9 @@ quant_rowwise_long_kernel(const char *__restrict__ x, int8_t *__restrict__ q, vo
 // colwise: memory matrix [P][Q] (Q contiguous); logical rows are the Q columns, the reduction
 // runs over P.  Block = 32 column-lanes (VEC columns each) x 8 row-lanes over a PB-row slab.
 // ------------------------------------------------------------------------------------------
-constexpr int COL_PB = 128;   // rows per block
+// PB = rows per block: 128 for large matrices, 32 when 128-row slabs would leave the chip under-filled
 
-template <int DT>
+template <int DT, int COL_PB>
 __global__ void __launch_bounds__(256)
 col_absmax_kernel(const char *__restrict__ x, unsigned *__restrict__ amax_ws, int64_t P, int64_t Q,
                   int64_t ld_bytes) {
@@ -222,7 +222,7 @@ col_absmax_kernel(const char *__restrict__ x, unsigned *__restrict__ amax_ws, in
     }
 }
 
-template <int DT, bool SR>
+template <int DT, bool SR, int COL_PB>
 __global__ void __launch_bounds__(256)
 col_quant_kernel(const char *__restrict__ x, int8_t *__restrict__ q, void *__restrict__ scale,
                  const unsigned *__restrict__ amax_ws, int64_t P, int64_t Q, int64_t ld_bytes,
@@ -336,10 +336,17 @@ int launch_colwise(const void *x, int8_t *q, void *scale, int64_t P, int64_t Q, 
     constexpr int VEC = ElemTraits<DT>::VEC;
     const int64_t ld_bytes = ld * (16 / VEC);
     if (hipMemsetAsync(ws, 0, (size_t)Q * 4, st) != hipSuccess) return gnk_fail(GNK_ERR_LAUNCH, "quantize_int8: memset of workspace failed");
-    const dim3 grid((unsigned)((Q + 32 * VEC - 1) / (32 * VEC)), (unsigned)((P + COL_PB - 1) / COL_PB)), block(256);
-    hipLaunchKernelGGL((col_absmax_kernel<DT>), grid, block, 0, st, (const char *)x, ws, P, Q, ld_bytes);
-    hipLaunchKernelGGL((col_quant_kernel<DT, SR>), grid, block, 0, st, (const char *)x, q, scale, ws, P, Q, ld_bytes, ldq,
-                       eps, seed, offset);
+    const int64_t gx = (Q + 32 * VEC - 1) / (32 * VEC);
+    const dim3 block(256);
+    if (gx * ((P + 127) / 128) * 2 >= (int64_t)gnk_num_cus()) {   // measured: 128-row slabs win down to 1 block per CU (4096^2, 8192 x 1024)
+        const dim3 grid((unsigned)gx, (unsigned)((P + 127) / 128));
+        hipLaunchKernelGGL((col_absmax_kernel<DT, 128>), grid, block, 0, st, (const char *)x, ws, P, Q, ld_bytes);
+        hipLaunchKernelGGL((col_quant_kernel<DT, SR, 128>), grid, block, 0, st, (const char *)x, q, scale, ws, P, Q, ld_bytes, ldq, eps, seed, offset);
+    } else {
+        const dim3 grid((unsigned)gx, (unsigned)((P + 31) / 32));
+        hipLaunchKernelGGL((col_absmax_kernel<DT, 32>), grid, block, 0, st, (const char *)x, ws, P, Q, ld_bytes);
+        hipLaunchKernelGGL((col_quant_kernel<DT, SR, 32>), grid, block, 0, st, (const char *)x, q, scale, ws, P, Q, ld_bytes, ldq, eps, seed, offset);
+    }
     return gnk_check_launch("quantize_int8 colwise");
 }
 

@@ -66,7 +66,7 @@ def check(rc: int, what: str) -> None:
 
 def stream_of(t: torch.Tensor) -> int:
     """hipStream_t of the calling thread's current stream on t's device."""
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return torch._C._cuda_getCurrentRawStream(t.device.index)   # 0.1 us; torch.cuda.current_stream() builds a Stream object (2 us)
 
 
 class device_of:

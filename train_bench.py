@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""Llama INT8 mixed-precision pre-training step throughput (tok/s) -- BASELINE.json configs[3] / configs[4].
+
+Restates the harness part of the reference's llm_pretrain.py (model build :100-124, DDP wrap :126-132, AdamW
+:57-59,144, loss :30-36, tok/s = batch_size * seq_len * steps / dt :229-234) around this repository's
+`subclasses.convert_mixed_precision` and `gn_kernels` ops; synthetic tokens stand in for the dataset and the weights
+are random-init (no network here).  The Llama architecture itself comes from `transformers` (as in the reference).
+
+  python train_bench.py --model 470m --quantize mixed_precision                       # configs[3], 1 GPU
+  python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 train_bench.py --model 1b --batch_size 16
+                                                                                      # configs[4]: global batch 16, DDP over RCCL
+"Llama2-1B" is not defined in the reference tree: this harness ASSUMES hidden 2048, intermediate
+5632, 22 layers, 32 heads (~1.1 B parameters, the TinyLlama shape) and says so in its output.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+from torch import nn
+
+ROOT = Path(__file__).resolve().parent
+sys.path[:0] = [str(ROOT / "quantized-training_amd"), str(ROOT)]
+
+MODELS = {
+    # mini_llamas/Llama-2-470m/config.json:5-10 of the reference
+    "470m": dict(hidden_size=1024, intermediate_size=4096, num_attention_heads=16, num_hidden_layers=24, num_key_value_heads=16),
+    # assumption, see module docstring
+    "1b": dict(hidden_size=2048, intermediate_size=5632, num_attention_heads=32, num_hidden_layers=22, num_key_value_heads=32),
+    "tiny": dict(hidden_size=256, intermediate_size=512, num_attention_heads=4, num_hidden_layers=2, num_key_value_heads=4),
+}
+
+
+def build_model(name, seq_len, device):
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from transformers.models.llama.modeling_llama import LlamaRMSNorm
+
+    cfg = LlamaConfig(vocab_size=32000, rms_norm_eps=1e-5, max_position_embeddings=seq_len, use_cache=False, **MODELS[name])
+    model = LlamaForCausalLM(cfg)
+    for m in model.modules():   # llm_pretrain.py:116-118: RoPE cache stays fp32
+        if isinstance(m, (nn.Linear, nn.Embedding, LlamaRMSNorm)):
+            m.bfloat16()
+    return model.to(device)
+
+
+def get_loss(model, tokens, labels):   # llm_pretrain.py:30-36
+    logits = model(tokens).logits.float()
+    return F.cross_entropy(logits.view(-1, logits.shape[-1]), labels.long().view(-1))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="470m", choices=list(MODELS))
+    ap.add_argument("--quantize", default="mixed_precision", choices=["none", "mixed_precision", "int8"])
+    ap.add_argument("--batch_size", type=int, default=4, help="GLOBAL batch (split over ranks as llm_pretrain.py:93,151)")
+    ap.add_argument("--seq_len", type=int, default=2048)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--lr", type=float, default=3e-4)
+    ap.add_argument("--weight_decay", type=float, default=1e-2)
+    ap.add_argument("--activation_checkpointing", action="store_true")
+    ap.add_argument("--device", default="cuda")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    on_gpu = args.device == "cuda"
+    dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl" if on_gpu else "gloo", **({"device_id": dev} if on_gpu else {}))
+    assert args.batch_size % world == 0
+    bsize = args.batch_size // world
+    torch.manual_seed(1234 + rank)
+
+    model = build_model(args.model, args.seq_len, dev)
+    if args.activation_checkpointing:
+        model.gradient_checkpointing_enable()
+    if args.quantize == "mixed_precision":
+        from subclasses import convert_mixed_precision
+
+        convert_mixed_precision(model.model)          # llm_pretrain.py:122 (lm_head stays bf16 unless --quantize_lm_head)
+    elif args.quantize == "int8":
+        from subclasses import convert_int8_quantized_training
+
+        convert_int8_quantized_training(model.model)
+    n_params = sum(p.numel() for p in model.parameters())
+    if world > 1:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+
+        model = DDP(model, device_ids=[local_rank] if on_gpu else None)
+    optim = torch.optim.AdamW(model.parameters(), lr=args.lr, weight_decay=args.weight_decay, fused=on_gpu and args.quantize != "int8")
+
+    def batch():
+        t = torch.randint(0, 32000, (bsize, args.seq_len + 1), device=dev)
+        return t[:, :-1].contiguous(), t[:, 1:].contiguous()
+
+    def step():
+        tokens, labels = batch()
+        loss = get_loss(model, tokens, labels)
+        loss.backward()
+        optim.step()
+        optim.zero_grad()
+        return loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    losses = []
+    for _ in range(args.warmup):
+        losses.append(step().item())
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    sync()
+    dt = time.perf_counter() - t0
+    losses.append(last.item())
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    if rank == 0:
+        toks = args.batch_size * args.seq_len * args.steps
+        lin = sum(m.in_features * m.out_features for m in model.modules() if isinstance(m, nn.Linear) and m.out_features != 32000)
+        out = {
+            "metric": "Llama INT8 mixed-precision training tok/s", "value": round(toks / dt, 1), "unit": "tok/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "strong", "dtype": "bf16 weights/activations; int8 MFMA in the Linear fwd / grad-input / grad-weight" if args.quantize != "none" else "bf16",
+            "data": "synthetic tokens, random-init weights",
+            "config": {"workload": f"llama-{args.model} {'(ASSUMED 1.1B shape: 2048/5632/22/32)' if args.model == '1b' else ''} global_batch {args.batch_size} x seq_len {args.seq_len}, "
+                                   f"quantize={args.quantize}, AdamW, {'DDP x%d (RCCL all-reduce)' % world if world > 1 else 'single GPU'}",
+                       "params": n_params, "body_linear_weights": lin},
+            "body_linear_TOPS": round(6 * args.batch_size * args.seq_len * lin * args.steps / dt * 1e-12, 1),
+            "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)],
+        }
+        if on_gpu:
+            out["max_mem_GiB"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
