@@ -96,6 +96,21 @@ int gnk_scaled_mm(const void *A, int a_dtype, const void *B, int b_dtype, void *
                   int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, void *stream);
 
 /*
+ * gnk_scaled_mm with an optional split-K workspace (no reference counterpart: Triton's autotuner has no split-K
+ * config, triton_mm.py:16-50).  For int8 products with a long K and few output tiles -- the grad-weight GEMM
+ * X.T @ dY of subclasses/mixed_precision.py:186 -- the K range is cut into chunks that run as separate workgroups;
+ * int32 partial tiles go to `workspace` and a second kernel adds them (exactly) and applies the scale epilogue, so
+ * the result is bit-identical to gnk_scaled_mm.  gnk_scaled_mm_workspace_bytes() returns the size the library
+ * would like for a problem (0: it would not split); a NULL or smaller workspace simply runs gnk_scaled_mm.
+ */
+int64_t gnk_scaled_mm_workspace_bytes(int a_dtype, int b_dtype, int64_t M, int64_t N, int64_t K);
+int gnk_scaled_mm_ws(const void *A, int a_dtype, const void *B, int b_dtype, void *C, int out_dtype,
+                     const void *row_scale, const void *col_scale, int scale_dtype,
+                     int col_scale_is_scalar, int order, int64_t M, int64_t N, int64_t K,
+                     int64_t sam, int64_t sak, int64_t sbk, int64_t sbn,
+                     void *workspace, int64_t workspace_bytes, void *stream);
+
+/*
  * Tile-scaled (2-D block scale) GEMM: for ascending K-blocks kb of QK elements
  *   acc_f32[m,n] += (f32(partial_kb[m,n]) * sA[m / QM, kb]) * sB[kb, n / QN]
  * with a fresh int32 / fp32 partial accumulator per K-block; multiply, multiply, add are separate

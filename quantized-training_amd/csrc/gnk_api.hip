@@ -104,7 +104,60 @@ struct GemmCall {
     const void *s0; const void *s1; int scale_dtype; int col_scalar; int order; int epi;
     int64_t M, N, K, sam, sak, sbk, sbn;
     int64_t ssam, ssak, ssbk, ssbn, QM, QN, QK;
+    void *ws; int64_t ws_bytes;   // optional split-K workspace (gnk_scaled_mm_ws)
 };
+
+// ---- split-K plan -------------------------------------------------------------------------------
+// Long-K products with few output tiles (the grad-weight GEMM X.T @ dY of a Linear: M = in, N = out, K = tokens) leave
+// most CUs idle with one workgroup per 128 x 128 tile (1024 x 1024 x 8192: 64 tiles on 256 CUs, 63 us).  Their K range
+// is cut into `splits` chunks, each workgroup writes an int32 partial tile into its own slab of the workspace and a
+// second kernel adds the slabs (exact: integers) and applies the scale epilogue.
+int plan_splits(int64_t M, int64_t N, int64_t K) {
+    if (K < 2048 || K % GNK_BK != 0) return 1;
+    const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    const int64_t capacity = (int64_t)gnk_num_cus() * 2;   // two 128 x 128 workgroups per CU
+    if (tiles * 2 > capacity) return 1;
+    int64_t s = capacity / tiles;
+    if (s > K / 1024) s = K / 1024;
+    if (s > 8) s = 8;
+    return s < 2 ? 1 : (int)s;
+}
+
+template <int OUT>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const int *__restrict__ ws, void *__restrict__ C, const void *__restrict__ s0,
+                                                            const void *__restrict__ s1, int64_t M, int64_t N, int splits, int scale_dtype,
+                                                            int col_scalar, int order) {
+    const int64_t quad = (int64_t)blockIdx.x * 256 + threadIdx.x;   // 4 consecutive n of one m (N % 4 == 0)
+    const int64_t idx = quad * 4;
+    if (idx >= M * N) return;
+    const int64_t m = idx / N, n = idx - m * N;
+    v4i acc = *(const v4i *)(ws + idx);
+    for (int s = 1; s < splits; ++s) {
+        const v4i part = *(const v4i *)(ws + (int64_t)s * M * N + idx);
+        acc += part;
+    }
+    const float rs = gnk_load_scalar_rt(s0, scale_dtype, m);
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float cs = gnk_load_scalar_rt(s1, scale_dtype, col_scalar ? 0 : n + r);
+        const float a = (float)acc[r];
+        v[r] = order == 0 ? __fmul_rn(__fmul_rn(a, rs), cs) : __fmul_rn(__fmul_rn(a, cs), rs);
+    }
+    if constexpr (OUT == GNK_F32) {
+        *(v4f *)((float *)C + idx) = (v4f){v[0], v[1], v[2], v[3]};
+    } else {
+        v2i o;
+        if constexpr (OUT == GNK_BF16) {
+            o[0] = (int)((unsigned)gnk_f32_to_bf16(v[0]) | ((unsigned)gnk_f32_to_bf16(v[1]) << 16));
+            o[1] = (int)((unsigned)gnk_f32_to_bf16(v[2]) | ((unsigned)gnk_f32_to_bf16(v[3]) << 16));
+        } else {
+            o[0] = (int)((unsigned)gnk_f32_to_f16(v[0]) | ((unsigned)gnk_f32_to_f16(v[1]) << 16));
+            o[1] = (int)((unsigned)gnk_f32_to_f16(v[2]) | ((unsigned)gnk_f32_to_f16(v[3]) << 16));
+        }
+        *(v2i *)((unsigned short *)C + idx) = o;
+    }
+}
 
 int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
     if (c.M < 0 || c.N < 0 || c.K < 0) return gnk_fail(GNK_ERR_BAD_ARG, "%s: negative dimension", name);
@@ -165,6 +218,29 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
         return gnk_launch_generic(op, fa, fb, g, st);
     }
 
+    // split-K: int8 row/col-scaled product, fast layout, 128 x 128 variant, workspace offered and large enough
+    if (c.ws && op == OP_I8 && c.epi == EPI_ROWCOL && ok_128 && g_forced_variant < 0 && c.N % 4 == 0 && ((uintptr_t)c.C & 15) == 0 &&
+        ((uintptr_t)c.ws & 15) == 0) {
+        const int splits = plan_splits(c.M, c.N, c.K);
+        if (splits > 1 && c.ws_bytes >= (int64_t)splits * c.M * c.N * 4) {
+            GemmParams p;
+            memset(&p, 0, sizeof(p));
+            p.A = (const char *)c.A; p.B = (const char *)c.B; p.C = c.ws;
+            p.M = c.M; p.N = c.N; p.K = c.K; p.lda = la.ld; p.ldb = lb.ld; p.out_dtype = GNK_I32;
+            p.kchunk = ((c.K / GNK_BK + splits - 1) / splits) * GNK_BK;
+            rc = gnk_launch_i8_v1(la.kmajor, lb.kmajor, EPI_PLAIN, p, st);
+            if (rc) return rc;
+            const int nsplit = (int)((c.K + p.kchunk - 1) / p.kchunk);
+            const unsigned blocks = (unsigned)((c.M * c.N / 4 + 255) / 256);
+#define GNK_REDUCE(OUT) hipLaunchKernelGGL((splitk_reduce_kernel<OUT>), dim3(blocks), dim3(256), 0, st, (const int *)c.ws, c.C, c.s0, c.s1, c.M, c.N, nsplit, c.scale_dtype, c.col_scalar, c.order)
+            if (c.out_dtype == GNK_BF16) GNK_REDUCE(GNK_BF16);
+            else if (c.out_dtype == GNK_F16) GNK_REDUCE(GNK_F16);
+            else GNK_REDUCE(GNK_F32);
+#undef GNK_REDUCE
+            return gnk_check_launch("scaled_mm split-K reduction");
+        }
+    }
+
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = (const char *)c.A; p.B = (const char *)c.B; p.C = c.C; p.s0 = c.s0; p.s1 = c.s1;
@@ -196,6 +272,26 @@ extern "C" int gnk_scaled_mm(const void *A, int a_dtype, const void *B, int b_dt
     c.s0 = row_scale; c.s1 = col_scale; c.scale_dtype = scale_dtype; c.col_scalar = col_scale_is_scalar != 0;
     c.order = order != 0; c.epi = EPI_ROWCOL;
     c.M = M; c.N = N; c.K = K; c.sam = sam; c.sak = sak; c.sbk = sbk; c.sbn = sbn;
+    return run_gemm("scaled_mm", c, (hipStream_t)stream);
+}
+
+extern "C" int64_t gnk_scaled_mm_workspace_bytes(int a_dtype, int b_dtype, int64_t M, int64_t N, int64_t K) {
+    if (a_dtype != GNK_I8 || b_dtype != GNK_I8 || M <= 0 || N <= 0) return 0;
+    const int splits = plan_splits(M, N, K);
+    return splits > 1 ? (int64_t)splits * M * N * 4 : 0;
+}
+
+extern "C" int gnk_scaled_mm_ws(const void *A, int a_dtype, const void *B, int b_dtype, void *C, int out_dtype,
+                                const void *row_scale, const void *col_scale, int scale_dtype, int col_scale_is_scalar,
+                                int order, int64_t M, int64_t N, int64_t K, int64_t sam, int64_t sak, int64_t sbk,
+                                int64_t sbn, void *workspace, int64_t workspace_bytes, void *stream) {
+    GemmCall c;
+    memset(&c, 0, sizeof(c));
+    c.A = A; c.a_dtype = a_dtype; c.B = B; c.b_dtype = b_dtype; c.C = C; c.out_dtype = out_dtype;
+    c.s0 = row_scale; c.s1 = col_scale; c.scale_dtype = scale_dtype; c.col_scalar = col_scale_is_scalar != 0;
+    c.order = order != 0; c.epi = EPI_ROWCOL;
+    c.M = M; c.N = N; c.K = K; c.sam = sam; c.sak = sak; c.sbk = sbk; c.sbn = sbn;
+    c.ws = workspace; c.ws_bytes = workspace ? workspace_bytes : 0;
     return run_gemm("scaled_mm", c, (hipStream_t)stream);
 }
 

@@ -40,6 +40,7 @@ struct GemmParams {
     int64_t QM, QN;                   // tile-scale block sizes along M and N (QK == 128)
     int out_dtype, scale_dtype, col_scalar, order;
     int grid_m, grid_n;
+    int64_t kchunk;   // split-K: k elements per split (gridDim.y splits, each writing its own (M, N) int32 slab at C); 0 = no split
     int debug;        // timing-ablation flags (gnk_set_debug_flags): 1 = no LDS-DMA in the main loop, 2 = no MFMA, 4 = no LDS reads
 };
 
@@ -432,10 +433,25 @@ template <class Cfg> struct TileScaleIdx {
 
 // ------------------------------------------------------------------------------ the kernel
 template <class Cfg>
-__global__ void __launch_bounds__(Cfg::NT) gemm_kernel(const GemmParams p) {
+__global__ void __launch_bounds__(Cfg::NT) gemm_kernel(const GemmParams p_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MT = Cfg::MT, NTL = Cfg::NTL;
     typedef typename AccT<Cfg::OP>::type acc_t;
+
+    // split-K (plain int32 output only): split s = blockIdx.y covers k in [s * kchunk, min(K, (s+1) * kchunk)) and
+    // owns slab s of the workspace; integer partial sums add exactly, so the reduction kernel's result is bit-identical
+    // to the unsplit product.  All of this is wave-uniform scalar arithmetic.
+    GemmParams p = p_in;
+    if constexpr (Cfg::EPI == EPI_PLAIN && Cfg::OP == OP_I8) {
+        if (p.kchunk > 0) {
+            const int64_t k0 = (int64_t)blockIdx.y * p.kchunk;
+            const int64_t kn = p_in.K - k0 < p.kchunk ? p_in.K - k0 : p.kchunk;
+            p.K = kn > 0 ? kn : 0;
+            p.A += Cfg::A_KMAJOR ? k0 : k0 * p.lda;
+            p.B += Cfg::B_KMAJOR ? k0 : k0 * p.ldb;
+            p.C = (char *)p.C + (int64_t)blockIdx.y * p.M * p.N * 4;
+        }
+    }
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -481,8 +497,10 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_kernel(const GemmParams p) {
     }
 
     const int nk = (int)(p.K / GNK_BK);
-    sa.issue(As0, wave);
-    sb.issue(Bs0, wave);
+    if (nk > 0) {
+        sa.issue(As0, wave);
+        sb.issue(Bs0, wave);
+    }
     for (int t = 0; t < nk; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -539,7 +557,8 @@ template <class Cfg> int launch(const GemmParams &p0, hipStream_t st) {
             return gnk_fail(GNK_ERR_LAUNCH, "gemm: cannot reserve %d bytes of LDS", Cfg::LDS_BYTES);
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<Cfg>), dim3((unsigned)(p.grid_m * p.grid_n)), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p);
+    const unsigned splits = p.kchunk > 0 ? (unsigned)((p.K + p.kchunk - 1) / p.kchunk) : 1u;
+    hipLaunchKernelGGL((gemm_kernel<Cfg>), dim3((unsigned)(p.grid_m * p.grid_n), splits), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p);
     return gnk_check_launch("gemm");
 }
 

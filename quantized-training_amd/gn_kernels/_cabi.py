@@ -50,6 +50,9 @@ def load() -> ctypes.CDLL:
     L.gnk_quantize_int8_workspace_bytes.restype = i64
     L.gnk_int8_mm.argtypes = [vp, vp, vp] + [i64] * 7 + [vp]
     L.gnk_scaled_mm.argtypes = [vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci] + [i64] * 7 + [vp]
+    L.gnk_scaled_mm_ws.argtypes = [vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci] + [i64] * 7 + [vp, i64, vp]
+    L.gnk_scaled_mm_workspace_bytes.argtypes = [ci, ci, i64, i64, i64]
+    L.gnk_scaled_mm_workspace_bytes.restype = i64
     L.gnk_tile_scaled_mm.argtypes = [vp, ci, vp, ci, vp, ci, vp, vp, ci] + [i64] * 14 + [vp]
     L.gnk_fp8_mm.argtypes = [vp, ci, vp, ci, vp, ci] + [i64] * 7 + [vp]
     if L.gnk_abi_version() != ABI_VERSION:

@@ -108,9 +108,17 @@ def _scaled_mm_launch(A: Tensor, B: Tensor, row_scale: Tensor, col_scale: Tensor
     L = _cabi.load()
     code = _cabi.DTYPE_CODE
     with _cabi.device_of(A):
-        rc = L.gnk_scaled_mm(A.data_ptr(), code[A.dtype], B.data_ptr(), code[B.dtype], C.data_ptr(), code[out_dtype],
-                             row_scale.data_ptr(), col_scale.data_ptr(), code[row_scale.dtype], int(col_scale.numel() == 1),
-                             order, M, N, K, *A.stride(), *B.stride(), _cabi.stream_of(A))
+        # long K, small output (grad-weight shapes): offer the library a split-K workspace if it wants one
+        ws_bytes = L.gnk_scaled_mm_workspace_bytes(code[A.dtype], code[B.dtype], M, N, K) if (K >= 2048 and A.dtype is torch.int8) else 0
+        if ws_bytes > 0:
+            ws = torch.empty(ws_bytes, device=A.device, dtype=torch.uint8)
+            rc = L.gnk_scaled_mm_ws(A.data_ptr(), code[A.dtype], B.data_ptr(), code[B.dtype], C.data_ptr(), code[out_dtype],
+                                    row_scale.data_ptr(), col_scale.data_ptr(), code[row_scale.dtype], int(col_scale.numel() == 1),
+                                    order, M, N, K, *A.stride(), *B.stride(), ws.data_ptr(), ws_bytes, _cabi.stream_of(A))
+        else:
+            rc = L.gnk_scaled_mm(A.data_ptr(), code[A.dtype], B.data_ptr(), code[B.dtype], C.data_ptr(), code[out_dtype],
+                                 row_scale.data_ptr(), col_scale.data_ptr(), code[row_scale.dtype], int(col_scale.numel() == 1),
+                                 order, M, N, K, *A.stride(), *B.stride(), _cabi.stream_of(A))
     _cabi.check(rc, op)
     return C
 

@@ -23,7 +23,7 @@ def declared_symbols():
 def test_header_declares_the_expected_entry_points():
     syms = declared_symbols()
     for s in ["gnk_quantize_int8", "gnk_int8_mm", "gnk_scaled_mm", "gnk_tile_scaled_mm", "gnk_fp8_mm", "gnk_last_error",
-              "gnk_abi_version", "gnk_init"]:
+              "gnk_abi_version", "gnk_init", "gnk_scaled_mm_ws", "gnk_scaled_mm_workspace_bytes"]:
         assert s in syms
 
 

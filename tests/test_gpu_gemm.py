@@ -205,6 +205,34 @@ def test_four_stage_kernel_k64_multiples_and_ragged_edges(shape, layout):
         L.gnk_set_gemm_variant(-1)
 
 
+@pytest.mark.parametrize("shape", [(1024, 1024, 8192), (384, 640, 4096), (1024, 4096, 2048), (130, 260, 2176)])
+@pytest.mark.parametrize("layout", list(LAYOUTS))
+def test_split_k_is_bit_identical(shape, layout):
+    """Long K with few output tiles (the grad-weight GEMM shapes): the op offers a workspace, the library splits K,
+    and the result must equal the oracle -- and the unsplit kernel -- bit for bit (integer partial sums)."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    acm, bcm = LAYOUTS[layout]
+    if (acm and M % 16) or ((not bcm) and N % 16):
+        pytest.skip("fast path needs 16-byte aligned leading dimensions")
+    A = to_layout(torch.randint(-128, 128, (M, K), dtype=torch.int8, generator=g), acm)
+    B = to_layout(torch.randint(-128, 128, (K, N), dtype=torch.int8, generator=g), bcm)
+    rs = torch.randn(M, 1, generator=g).div(128).bfloat16()
+    cs = torch.randn(1, N, generator=g).div(128).bfloat16()
+    L = _cabi.load()
+    want_ws = L.gnk_scaled_mm_workspace_bytes(_cabi.I8, _cabi.I8, M, N, K)
+    assert want_ws > 0 and want_ws % (M * N * 4) == 0, "these shapes are meant to take the split-K path"
+    Ad, Bd = dev_layout(A, acm), dev_layout(B, bcm)
+    for r, c in ((rs, cs), (rs.float(), cs.float()), (rs.half(), cs[:, :1].half().contiguous())):
+        got = gn_kernels.scaled_mm(Ad, Bd, r.to(DEV), c.to(DEV))
+        assert bits_equal(got, oracle.scaled_mm(A, B, r, c))
+        L.gnk_set_gemm_variant(1)            # forced variant = never split
+        try:
+            assert bits_equal(got, gn_kernels.scaled_mm(Ad, Bd, r.to(DEV), c.to(DEV)))
+        finally:
+            L.gnk_set_gemm_variant(-1)
+
+
 def test_errors_surface_as_exceptions():
     A = torch.zeros(4, 8, dtype=torch.int8, device=DEV)
     with pytest.raises(RuntimeError):
