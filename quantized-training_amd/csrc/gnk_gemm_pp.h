@@ -141,6 +141,9 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(const GemmParams p) {
     tile_of_block(p.grid_m, p.grid_n, tm, tn);
     const int64_t m0 = (int64_t)tm * 256, n0 = (int64_t)tn * 256;
 
+    ScalePrefetch<256, 256, 512, Cfg::EPI> spf;
+    spf.issue(p, m0, n0);
+
     typename K::StA sa;
     typename K::StB sb;
     sa.init(p.A, p.lda, m0, p.M, wave, lane);
@@ -180,13 +183,17 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(const GemmParams p) {
     if (t < nk) K::template kstep<0>(smem, t, nk, acc, fa, fb, sa, sb, wave, wm, wn, lane, dbg);
     if (wm == 0) __builtin_amdgcn_s_barrier();           // pay the stagger back so barrier counts match
     __builtin_amdgcn_sched_barrier(0);
+    spf.park(p, smem + Cfg::LDS_BYTES);
+    __syncthreads();                                     // scales parked in LDS are visible to every wave
 
     // all LDS tile reads retired at the last barrier; each wave stages its result through its own LDS slice
     v4f(*no_accf)[1] = nullptr;
-    run_epilogue<Cfg>(p, acc, no_accf, smem, wave, lane, m0 + wm * 128, n0 + wn * 64);
+    run_epilogue<Cfg>(p, acc, no_accf, smem, wave, lane, m0 + wm * 128, n0 + wn * 64,
+                      Cfg::EPI == EPI_ROWCOL ? (const float *)(smem + Cfg::LDS_BYTES) : nullptr, wm * 128, wn * 64);
 }
 
 template <class Cfg> int launch_pp(const GemmParams &p0, hipStream_t st) {
+    constexpr int LDS_TOTAL = Cfg::LDS_BYTES + ScalePrefetch<256, 256, 512, Cfg::EPI>::BYTES;
     GemmParams p = p0;
     p.grid_m = (int)((p.M + 255) / 256);
     p.grid_n = (int)((p.N + 255) / 256);
@@ -194,11 +201,11 @@ template <class Cfg> int launch_pp(const GemmParams &p0, hipStream_t st) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return gnk_fail(GNK_ERR_LAUNCH, "gemm: no current HIP device");
     if (!attr_set[dev]) {
-        if (hipFuncSetAttribute((const void *)gemm_pp_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess)
-            return gnk_fail(GNK_ERR_LAUNCH, "gemm: cannot reserve %d bytes of LDS", Cfg::LDS_BYTES);
+        if (hipFuncSetAttribute((const void *)gemm_pp_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess)
+            return gnk_fail(GNK_ERR_LAUNCH, "gemm: cannot reserve %d bytes of LDS", LDS_TOTAL);
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((gemm_pp_kernel<Cfg>), dim3((unsigned)(p.grid_m * p.grid_n)), dim3(512), Cfg::LDS_BYTES, st, p);
+    hipLaunchKernelGGL((gemm_pp_kernel<Cfg>), dim3((unsigned)(p.grid_m * p.grid_n)), dim3(512), LDS_TOTAL, st, p);
     return gnk_check_launch("gemm (ping-pong)");
 }
 

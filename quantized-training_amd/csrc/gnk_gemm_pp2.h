@@ -96,9 +96,10 @@ template <class Cfg> struct PP2I8 {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (v4i){0, 0, 0, 0};
     }
-    static __device__ __forceinline__ void finish(const GemmParams &p, acc_arr &acc, char *smem, int wave, int lane, int64_t mwave, int64_t nwave) {
+    static __device__ __forceinline__ void finish(const GemmParams &p, acc_arr &acc, char *smem, int wave, int lane, int64_t mwave, int64_t nwave,
+                                                  const float *lsc, int mlw, int nlw) {
         v4f(*no_accf)[1] = nullptr;
-        run_epilogue<ECfg>(p, acc, no_accf, smem, wave, lane, mwave, nwave);
+        run_epilogue<ECfg>(p, acc, no_accf, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
     }
     template <bool KMAJOR> static __device__ __forceinline__ v4i load_frag16(const char *stage, int rb, int lane) {
         if constexpr (KMAJOR) {
@@ -187,24 +188,6 @@ template <class Cfg> struct PP2F8 {
 
     // ------------------------------------------------------------------ epilogue (32 x 32 tile maps)
     // lane: m = mwave + 32 i + (lane & 31);  n = nwave + 32 j + 8 g + 4 h + r  with reg = 4 g + r, h = lane >> 5
-    template <int SDT>
-    static __device__ __forceinline__ void load_scales(const GemmParams &p, float (&rs)[4], float (&cs)[2][4][4], int64_t mwave, int64_t nwave, int lane) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t m = mwave + 32 * i + (lane & 31);
-            rs[i] = gnk_load_scalar<SDT>(p.s0, m < p.M ? m : p.M - 1);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t n = nwave + 32 * j + 8 * g + 4 * (lane >> 5) + r;
-                    cs[j][g][r] = gnk_load_scalar<SDT>(p.s1, p.col_scalar ? 0 : (n < p.N ? n : p.N - 1));
-                }
-    }
-
     static __device__ __forceinline__ float value(const GemmParams &p, const acc_t &a, int reg, float rs, float cs) {
         float x;
         if constexpr (Cfg::OP == OP_I8) x = (float)a[reg];   // v_cvt_f32_i32: RNE
@@ -214,12 +197,19 @@ template <class Cfg> struct PP2F8 {
     }
 
     template <int OUT, int MODE>   // MODE 0: LDS-staged 16-byte stores (2-byte outputs); 1: direct vector; 2: direct scalar
-    static __device__ __forceinline__ void epilogue(const GemmParams &p, acc_t (&acc)[4][2], char *smem, int wave, int lane, int64_t mwave, int64_t nwave) {
+    static __device__ __forceinline__ void epilogue(const GemmParams &p, acc_t (&acc)[4][2], char *smem, int wave, int lane, int64_t mwave, int64_t nwave,
+                                                    const float *lsc, int mlw, int nlw) {
         float rs[4], cs[2][4][4];
-        if constexpr (Cfg::EPI == EPI_ROWCOL) {
-            if (p.scale_dtype == GNK_BF16) load_scales<GNK_BF16>(p, rs, cs, mwave, nwave, lane);
-            else if (p.scale_dtype == GNK_F16) load_scales<GNK_F16>(p, rs, cs, mwave, nwave, lane);
-            else load_scales<GNK_F32>(p, rs, cs, mwave, nwave, lane);
+        if constexpr (Cfg::EPI == EPI_ROWCOL) {   // scales were prefetched into LDS at kernel start (ScalePrefetch): rows, then columns
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rs[i] = *(const GNK_LDS float *)(lsc + mlw + 32 * i + (lane & 31));
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const v4f c = *(const GNK_LDS v4f *)(lsc + 256 + nlw + 32 * j + 8 * g + 4 * (lane >> 5));
+                    cs[j][g][0] = c[0]; cs[j][g][1] = c[1]; cs[j][g][2] = c[2]; cs[j][g][3] = c[3];
+                }
         }
         const int ml = lane & 31, h = lane >> 5;
         char *const region = smem + wave * (128 * 128);   // this wave's 128 rows x 128 B result slice
@@ -260,23 +250,24 @@ template <class Cfg> struct PP2F8 {
             }
         }
     }
-    static __device__ __forceinline__ void finish(const GemmParams &p, acc_arr &acc, char *smem, int wave, int lane, int64_t mwave, int64_t nwave) {
+    static __device__ __forceinline__ void finish(const GemmParams &p, acc_arr &acc, char *smem, int wave, int lane, int64_t mwave, int64_t nwave,
+                                                  const float *lsc, int mlw, int nlw) {
         const bool aligned16 = ((uintptr_t)p.C & 15) == 0;
         const bool vec_ok = (p.N % 4 == 0) && aligned16, lds_ok = (p.N % 8 == 0) && aligned16;
         if constexpr (Cfg::EPI == EPI_PLAIN && Cfg::OP == OP_I8) {
-            if (vec_ok) epilogue<GNK_I32, 1>(p, acc, smem, wave, lane, mwave, nwave);
-            else epilogue<GNK_I32, 2>(p, acc, smem, wave, lane, mwave, nwave);
+            if (vec_ok) epilogue<GNK_I32, 1>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
+            else epilogue<GNK_I32, 2>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
         } else if (p.out_dtype == GNK_BF16) {
-            if (lds_ok) epilogue<GNK_BF16, 0>(p, acc, smem, wave, lane, mwave, nwave);
-            else if (vec_ok) epilogue<GNK_BF16, 1>(p, acc, smem, wave, lane, mwave, nwave);
-            else epilogue<GNK_BF16, 2>(p, acc, smem, wave, lane, mwave, nwave);
+            if (lds_ok) epilogue<GNK_BF16, 0>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
+            else if (vec_ok) epilogue<GNK_BF16, 1>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
+            else epilogue<GNK_BF16, 2>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
         } else if (p.out_dtype == GNK_F16) {
-            if (lds_ok) epilogue<GNK_F16, 0>(p, acc, smem, wave, lane, mwave, nwave);
-            else if (vec_ok) epilogue<GNK_F16, 1>(p, acc, smem, wave, lane, mwave, nwave);
-            else epilogue<GNK_F16, 2>(p, acc, smem, wave, lane, mwave, nwave);
+            if (lds_ok) epilogue<GNK_F16, 0>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
+            else if (vec_ok) epilogue<GNK_F16, 1>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
+            else epilogue<GNK_F16, 2>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
         } else {
-            if (vec_ok) epilogue<GNK_F32, 1>(p, acc, smem, wave, lane, mwave, nwave);
-            else epilogue<GNK_F32, 2>(p, acc, smem, wave, lane, mwave, nwave);
+            if (vec_ok) epilogue<GNK_F32, 1>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
+            else epilogue<GNK_F32, 2>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
         }
     }
 };
@@ -296,6 +287,9 @@ __global__ void __launch_bounds__(512) gemm_pp2_kernel(const GemmParams p) {
     int tm, tn;
     tile_of_block(p.grid_m, p.grid_n, tm, tn);
     const int64_t m0 = (int64_t)tm * 256, n0 = (int64_t)tn * 256;
+
+    ScalePrefetch<256, 256, 512, Cfg::EPI> spf;
+    spf.issue(p, m0, n0);
 
     Stager64<Cfg::A_KMAJOR> sa;
     Stager64<Cfg::B_KMAJOR> sb;
@@ -354,10 +348,13 @@ __global__ void __launch_bounds__(512) gemm_pp2_kernel(const GemmParams p) {
 
     // all LDS stage reads retired at the last barrier; each wave stages its result through its own LDS slice
     const int64_t mwave = m0 + wm * 128, nwave = n0 + wn * 64;
-    K::finish(p, acc, smem, wave, lane, mwave, nwave);
+    spf.park(p, smem + Cfg::LDS_BYTES);
+    __syncthreads();   // scales parked in LDS are visible to every wave
+    K::finish(p, acc, smem, wave, lane, mwave, nwave, Cfg::EPI == EPI_ROWCOL ? (const float *)(smem + Cfg::LDS_BYTES) : nullptr, wm * 128, wn * 64);
 }
 
 template <class Cfg> int launch_pp2(const GemmParams &p0, hipStream_t st) {
+    constexpr int LDS_TOTAL = Cfg::LDS_BYTES + ScalePrefetch<256, 256, 512, Cfg::EPI>::BYTES;
     GemmParams p = p0;
     p.grid_m = (int)((p.M + 255) / 256);
     p.grid_n = (int)((p.N + 255) / 256);
@@ -365,11 +362,11 @@ template <class Cfg> int launch_pp2(const GemmParams &p0, hipStream_t st) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return gnk_fail(GNK_ERR_LAUNCH, "gemm: no current HIP device");
     if (!attr_set[dev]) {
-        if (hipFuncSetAttribute((const void *)gemm_pp2_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess)
-            return gnk_fail(GNK_ERR_LAUNCH, "gemm: cannot reserve %d bytes of LDS", Cfg::LDS_BYTES);
+        if (hipFuncSetAttribute((const void *)gemm_pp2_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess)
+            return gnk_fail(GNK_ERR_LAUNCH, "gemm: cannot reserve %d bytes of LDS", LDS_TOTAL);
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((gemm_pp2_kernel<Cfg>), dim3((unsigned)(p.grid_m * p.grid_n)), dim3(512), Cfg::LDS_BYTES, st, p);
+    hipLaunchKernelGGL((gemm_pp2_kernel<Cfg>), dim3((unsigned)(p.grid_m * p.grid_n)), dim3(512), LDS_TOTAL, st, p);
     return gnk_check_launch("gemm (4-stage ping-pong)");
 }
 
