@@ -149,11 +149,11 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const int *__restric
     } else {
         v2i o;
         if constexpr (OUT == GNK_BF16) {
-            o[0] = (int)((unsigned)gnk_f32_to_bf16(v[0]) | ((unsigned)gnk_f32_to_bf16(v[1]) << 16));
-            o[1] = (int)((unsigned)gnk_f32_to_bf16(v[2]) | ((unsigned)gnk_f32_to_bf16(v[3]) << 16));
+            o[0] = (int)gnk_pack2_bf16(v[0], v[1]);
+            o[1] = (int)gnk_pack2_bf16(v[2], v[3]);
         } else {
-            o[0] = (int)((unsigned)gnk_f32_to_f16(v[0]) | ((unsigned)gnk_f32_to_f16(v[1]) << 16));
-            o[1] = (int)((unsigned)gnk_f32_to_f16(v[2]) | ((unsigned)gnk_f32_to_f16(v[3]) << 16));
+            o[0] = (int)gnk_pack2_f16(v[0], v[1]);
+            o[1] = (int)gnk_pack2_f16(v[2], v[3]);
         }
         *(v2i *)((unsigned short *)C + idx) = o;
     }

@@ -37,17 +37,35 @@ static inline int gnk_dtype_size(int d) {
 // bf16 <-> f32 by bit manipulation: RNE, NaN stays NaN (matches torch's cast).
 __device__ __forceinline__ float gnk_bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 
+// fp32 -> bf16, round to nearest even, NaN stays NaN: gfx950's v_cvt_pk_bf16_f32 (one instruction per TWO values; the
+// integer-arithmetic version cost 8 VALU instructions per value and made the GEMM epilogue VALU-bound).
+typedef __bf16 gnk_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float gnk_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned gnk_pack2_bf16(float lo, float hi) {
+    const gnk_bf16x2 r = __builtin_convertvector((gnk_f32x2){lo, hi}, gnk_bf16x2);
+    unsigned u;
+    __builtin_memcpy(&u, &r, 4);
+    return u;
+}
 __device__ __forceinline__ unsigned short gnk_f32_to_bf16(float f) {
-    unsigned u = __float_as_uint(f);
-    unsigned r = u + 0x7fffu + ((u >> 16) & 1u);
-    r = ((u & 0x7fffffffu) > 0x7f800000u) ? (u | 0x00400000u) : r;
-    return (unsigned short)(r >> 16);
+    const __bf16 r = (__bf16)f;
+    unsigned short u;
+    __builtin_memcpy(&u, &r, 2);
+    return u;
 }
 
 __device__ __forceinline__ float gnk_f16_to_f32(unsigned short h) {
     _Float16 x;
     __builtin_memcpy(&x, &h, 2);
     return (float)x;
+}
+
+__device__ __forceinline__ unsigned gnk_pack2_f16(float lo, float hi) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 r = __builtin_convertvector((gnk_f32x2){lo, hi}, h2);   // round to nearest even (two v_cvt_f16_f32 + pack)
+    unsigned u;
+    __builtin_memcpy(&u, &r, 4);
+    return u;
 }
 
 __device__ __forceinline__ unsigned short gnk_f32_to_f16(float f) {

@@ -198,12 +198,12 @@ __device__ __forceinline__ void store4(void *C, int64_t m, int64_t n, int64_t M,
     const int64_t idx = m * N + n;
     if constexpr (VEC) {
         if constexpr (OUT == GNK_BF16) {
-            v2i o = {(int)((unsigned)gnk_f32_to_bf16(v0) | ((unsigned)gnk_f32_to_bf16(v1) << 16)),
-                     (int)((unsigned)gnk_f32_to_bf16(v2) | ((unsigned)gnk_f32_to_bf16(v3) << 16))};
+            v2i o = {(int)gnk_pack2_bf16(v0, v1),
+                     (int)gnk_pack2_bf16(v2, v3)};
             *(v2i *)((unsigned short *)C + idx) = o;
         } else if constexpr (OUT == GNK_F16) {
-            v2i o = {(int)((unsigned)gnk_f32_to_f16(v0) | ((unsigned)gnk_f32_to_f16(v1) << 16)),
-                     (int)((unsigned)gnk_f32_to_f16(v2) | ((unsigned)gnk_f32_to_f16(v3) << 16))};
+            v2i o = {(int)gnk_pack2_f16(v0, v1),
+                     (int)gnk_pack2_f16(v2, v3)};
             *(v2i *)((unsigned short *)C + idx) = o;
         } else if constexpr (OUT == GNK_I32) {
             *(v4i *)((int *)C + idx) = (v4i){__float_as_int(v0), __float_as_int(v1), __float_as_int(v2), __float_as_int(v3)};
@@ -354,31 +354,33 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams &p, typename AccT<
     const int g = lane >> 4, ml = lane & 15;
     EpiScales<Cfg> sc;
     sc.load(p, mwave + ml, nwave + 4 * g, lsc, mlw + ml, nlw + 4 * g);
+    // row block i (16 rows) is complete after its NTL tiles: its two 8-row store groups go out at once, so global
+    // stores overlap the conversion of the following row blocks (same wave wrote and reads its slice: in order)
 #pragma unroll
-    for (int j = 0; j < Cfg::NTL; ++j)
+    for (int i = 0; i < Cfg::MT; ++i) {
 #pragma unroll
-        for (int i = 0; i < Cfg::MT; ++i) {
+        for (int j = 0; j < Cfg::NTL; ++j) {
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = sc.value(p, acc[i][j], Cfg::EPI == EPI_TILE ? &accf[i][j] : nullptr, i, j, r);
             v2i o;
             if constexpr (OUT == GNK_BF16) {
-                o[0] = (int)((unsigned)gnk_f32_to_bf16(v[0]) | ((unsigned)gnk_f32_to_bf16(v[1]) << 16));
-                o[1] = (int)((unsigned)gnk_f32_to_bf16(v[2]) | ((unsigned)gnk_f32_to_bf16(v[3]) << 16));
+                o[0] = (int)gnk_pack2_bf16(v[0], v[1]);
+                o[1] = (int)gnk_pack2_bf16(v[2], v[3]);
             } else {
-                o[0] = (int)((unsigned)gnk_f32_to_f16(v[0]) | ((unsigned)gnk_f32_to_f16(v[1]) << 16));
-                o[1] = (int)((unsigned)gnk_f32_to_f16(v[2]) | ((unsigned)gnk_f32_to_f16(v[3]) << 16));
+                o[0] = (int)gnk_pack2_f16(v[0], v[1]);
+                o[1] = (int)gnk_pack2_f16(v[2], v[3]);
             }
             const int row = 16 * i + ml;
             *(GNK_LDS v2i *)(GNK_LDS char *)(region + row * 128 + (((2 * j + (g >> 1)) ^ (ml & 7)) << 4) + 8 * (g & 1)) = o;
         }
-    // same wave wrote and reads its slice: LDS operations of one wave complete in order
 #pragma unroll
-    for (int it = 0; it < Cfg::WTM / 8; ++it) {
-        const int row = it * 8 + (lane >> 3), c = lane & 7;
-        const v4i d = *(const GNK_LDS v4i *)(const GNK_LDS char *)(region + row * 128 + ((c ^ (row & 7)) << 4));
-        const int64_t m = mwave + row, n = nwave + 8 * c;
-        if (m < p.M && n < p.N) *(v4i *)((unsigned short *)p.C + m * p.N + n) = d;
+        for (int it = 2 * i; it < 2 * i + 2; ++it) {
+            const int row = it * 8 + (lane >> 3), c = lane & 7;
+            const v4i d = *(const GNK_LDS v4i *)(const GNK_LDS char *)(region + row * 128 + ((c ^ (row & 7)) << 4));
+            const int64_t m = mwave + row, n = nwave + 8 * c;
+            if (m < p.M && n < p.N) *(v4i *)((unsigned short *)p.C + m * p.N + n) = d;
+        }
     }
 }
 

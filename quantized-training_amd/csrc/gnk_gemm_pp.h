@@ -185,6 +185,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(const GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
     spf.park(p, smem + Cfg::LDS_BYTES);
     __syncthreads();                                     // scales parked in LDS are visible to every wave
+    if (dbg & 8) return;                                 // timing ablation: no epilogue at all
 
     // all LDS tile reads retired at the last barrier; each wave stages its result through its own LDS slice
     v4f(*no_accf)[1] = nullptr;

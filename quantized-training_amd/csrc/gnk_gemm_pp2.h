@@ -214,9 +214,9 @@ template <class Cfg> struct PP2F8 {
         const int ml = lane & 31, h = lane >> 5;
         char *const region = smem + wave * (128 * 128);   // this wave's 128 rows x 128 B result slice
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float v[4];
@@ -228,11 +228,11 @@ template <class Cfg> struct PP2F8 {
                     if constexpr (MODE == 0) {
                         v2i o;
                         if constexpr (OUT == GNK_BF16) {
-                            o[0] = (int)((unsigned)gnk_f32_to_bf16(v[0]) | ((unsigned)gnk_f32_to_bf16(v[1]) << 16));
-                            o[1] = (int)((unsigned)gnk_f32_to_bf16(v[2]) | ((unsigned)gnk_f32_to_bf16(v[3]) << 16));
+                            o[0] = (int)gnk_pack2_bf16(v[0], v[1]);
+                            o[1] = (int)gnk_pack2_bf16(v[2], v[3]);
                         } else {
-                            o[0] = (int)((unsigned)gnk_f32_to_f16(v[0]) | ((unsigned)gnk_f32_to_f16(v[1]) << 16));
-                            o[1] = (int)((unsigned)gnk_f32_to_f16(v[2]) | ((unsigned)gnk_f32_to_f16(v[3]) << 16));
+                            o[0] = (int)gnk_pack2_f16(v[0], v[1]);
+                            o[1] = (int)gnk_pack2_f16(v[2], v[3]);
                         }
                         const int row = 32 * i + ml;
                         *(GNK_LDS v2i *)(GNK_LDS char *)(region + row * 128 + (((4 * j + g) ^ (row & 7)) << 4) + 8 * h) = o;
@@ -240,13 +240,14 @@ template <class Cfg> struct PP2F8 {
                         store4<OUT, MODE == 1>(p.C, mwave + 32 * i + ml, nwave + 32 * j + 8 * g + 4 * h, p.M, p.N, v[0], v[1], v[2], v[3]);
                     }
                 }
-        if constexpr (MODE == 0) {
+            if constexpr (MODE == 0) {   // rows 32 i .. 32 i + 31 are complete: store them while the next row block converts
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int row = it * 8 + (lane >> 3), c = lane & 7;
-                const v4i d = *(const GNK_LDS v4i *)(const GNK_LDS char *)(region + row * 128 + ((c ^ (row & 7)) << 4));
-                const int64_t m = mwave + row, n = nwave + 8 * c;
-                if (m < p.M && n < p.N) *(v4i *)((unsigned short *)p.C + m * p.N + n) = d;
+                for (int it = 4 * i; it < 4 * i + 4; ++it) {
+                    const int row = it * 8 + (lane >> 3), c = lane & 7;
+                    const v4i d = *(const GNK_LDS v4i *)(const GNK_LDS char *)(region + row * 128 + ((c ^ (row & 7)) << 4));
+                    const int64_t m = mwave + row, n = nwave + 8 * c;
+                    if (m < p.M && n < p.N) *(v4i *)((unsigned short *)p.C + m * p.N + n) = d;
+                }
             }
         }
     }
