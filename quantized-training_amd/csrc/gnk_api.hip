@@ -2,6 +2,7 @@
 // dispatch between the LDS-DMA MFMA kernels and the generic fallback.
 #include "gnk_gemm_dispatch.h"
 
+#include <math.h>
 #include <string.h>
 
 // ------------------------------------------------------------------ error plumbing
@@ -107,20 +108,38 @@ struct GemmCall {
     void *ws; int64_t ws_bytes;   // optional split-K workspace (gnk_scaled_mm_ws)
 };
 
-// ---- split-K plan -------------------------------------------------------------------------------
-// Long-K products with few output tiles (the grad-weight GEMM X.T @ dY of a Linear: M = in, N = out, K = tokens) leave
-// most CUs idle with one workgroup per 128 x 128 tile (1024 x 1024 x 8192: 64 tiles on 256 CUs, 63 us).  Their K range
-// is cut into `splits` chunks, each workgroup writes an int32 partial tile into its own slab of the workspace and a
-// second kernel adds the slabs (exact: integers) and applies the scale epilogue.
-int plan_splits(int64_t M, int64_t N, int64_t K) {
-    if (K < 2048 || K % GNK_BK != 0) return 1;
-    const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
-    const int64_t capacity = (int64_t)gnk_num_cus() * 2;   // two 128 x 128 workgroups per CU
-    if (tiles * 2 > capacity) return 1;
-    int64_t s = capacity / tiles;
-    if (s > K / 1024) s = K / 1024;
-    if (s > 8) s = 8;
-    return s < 2 ? 1 : (int)s;
+// ---- kernel choice: a cost model fitted to MI355X measurements (tools/cmp_variants.py, tools/splitk_probe.py) ----------
+// Times in us.  A 256 x 256 workgroup (one per CU) costs ~15 fixed (launch, 4-stage prologue, 128 KiB result write) and
+// ~1.4 per 128 k; a round of 128 x 128 workgroups (two per CU) ~6 fixed and ~1.0 per 128 k.  Split-K (int8 row/col
+// epilogue, workspace offered): long-K products with few output tiles -- the grad-weight GEMM X.T @ dY of a Linear,
+// M = in, N = out, K = tokens -- leave most CUs idle (1024 x 1024 x 8192: 64 tiles, 63 us); their K range is cut into
+// `splits` chunks, each workgroup writes an int32 partial tile into its own slab of the workspace, and a second kernel
+// adds the slabs (exactly: integers) and applies the scale epilogue (~6 us + 8 B per element and split at ~4 TB/s).
+struct GemmPlan { int variant; int splits; };
+
+GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, bool can256, bool can128, bool can_split) {
+    const double cus = (double)gnk_num_cus();
+    const double ksteps = (double)K / 128.0;
+    GemmPlan best = {GNK_VARIANT_GENERIC, 1};
+    double best_t = 1e30;
+    if (can256) {
+        const double tiles = (double)(((M + 255) / 256) * ((N + 255) / 256));
+        const double t = ceil(tiles / cus) * (15.0 + 1.4 * ksteps);
+        if (t < best_t) { best_t = t; best = {GNK_VARIANT_256, 1}; }
+    }
+    if (can128) {
+        const double tiles = (double)(((M + 127) / 128) * ((N + 127) / 128));
+        const double t = ceil(tiles / (2.0 * cus)) * (6.0 + 1.0 * ksteps);
+        if (t < best_t) { best_t = t; best = {GNK_VARIANT_128, 1}; }
+        if (can_split && K >= 4096) {
+            for (int sp = 2; sp <= 8; sp *= 2) {
+                if (K / sp < 512) break;
+                const double ts = ceil(tiles * sp / (2.0 * cus)) * (6.0 + 1.0 * ksteps / sp) + 6.0 + (double)sp * (double)M * (double)N * 8.0 / 4.0e6;
+                if (ts < best_t) { best_t = ts; best = {GNK_VARIANT_128, sp}; }
+            }
+        }
+    }
+    return best;
 }
 
 template <int OUT>
@@ -195,15 +214,14 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
     const bool ok_128 = fast_layout && c.K >= GNK_BK && c.K % GNK_BK == 0 && tile_ok;
     if ((variant == GNK_VARIANT_256_SIMPLE || variant == GNK_VARIANT_256_PP8) && (op != OP_I8 || c.epi == EPI_TILE)) variant = GNK_VARIANT_256;
     if (variant == GNK_VARIANT_256 && c.epi == EPI_TILE) variant = GNK_VARIANT_128;
+    int splits = 1;
     if (variant < 0 || variant > GNK_VARIANT_LAST) {
-        // 256^2 tiles once they alone fill most of the chip, else 128^2 (2 workgroups / CU)
-        const int64_t big_tiles = ((c.M + 255) / 256) * ((c.N + 255) / 256);
-        if (ok_pp2 && (big_tiles * 10 >= (int64_t)gnk_num_cus() * 8 || !ok_128)) {
-            variant = GNK_VARIANT_256;
-            // int8 with both operands K-major: the 8-phase kernel measured 3-5 % ahead of the 4-stage one (61.5 vs 64.7 us at 4096^3)
-            if (op == OP_I8 && la.kmajor && lb.kmajor && ok_128) variant = GNK_VARIANT_256_PP8;
-        } else if (ok_128) variant = GNK_VARIANT_128;
-        else variant = GNK_VARIANT_GENERIC;
+        const bool can_split = c.ws && op == OP_I8 && c.epi == EPI_ROWCOL && ok_128 && c.N % 4 == 0 && ((uintptr_t)c.C & 15) == 0 && ((uintptr_t)c.ws & 15) == 0;
+        const GemmPlan plan = plan_gemm(c.M, c.N, c.K, ok_pp2, ok_128, can_split);
+        variant = plan.variant;
+        if (plan.splits > 1 && c.ws_bytes >= (int64_t)plan.splits * c.M * c.N * 4) splits = plan.splits;
+        // int8 with both operands K-major: the 8-phase kernel measured 3-5 % ahead of the 4-stage one (60.0 vs 64.0 us at 4096^3)
+        if (variant == GNK_VARIANT_256 && op == OP_I8 && la.kmajor && lb.kmajor && ok_128) variant = GNK_VARIANT_256_PP8;
     } else if (variant != GNK_VARIANT_GENERIC && !(variant == GNK_VARIANT_256 ? ok_pp2 : ok_128)) {
         return gnk_fail(GNK_ERR_UNSUPPORTED, "%s: forced fast variant %d cannot take these strides / sizes", name, variant);
     }
@@ -218,11 +236,9 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
         return gnk_launch_generic(op, fa, fb, g, st);
     }
 
-    // split-K: int8 row/col-scaled product, fast layout, 128 x 128 variant, workspace offered and large enough
-    if (c.ws && op == OP_I8 && c.epi == EPI_ROWCOL && ok_128 && g_forced_variant < 0 && c.N % 4 == 0 && ((uintptr_t)c.C & 15) == 0 &&
-        ((uintptr_t)c.ws & 15) == 0) {
-        const int splits = plan_splits(c.M, c.N, c.K);
-        if (splits > 1 && c.ws_bytes >= (int64_t)splits * c.M * c.N * 4) {
+    // split-K (planned above: int8 row/col-scaled product, fast layout, workspace offered and large enough)
+    if (splits > 1) {
+        {
             GemmParams p;
             memset(&p, 0, sizeof(p));
             p.A = (const char *)c.A; p.B = (const char *)c.B; p.C = c.ws;
@@ -277,8 +293,9 @@ extern "C" int gnk_scaled_mm(const void *A, int a_dtype, const void *B, int b_dt
 
 extern "C" int64_t gnk_scaled_mm_workspace_bytes(int a_dtype, int b_dtype, int64_t M, int64_t N, int64_t K) {
     if (a_dtype != GNK_I8 || b_dtype != GNK_I8 || M <= 0 || N <= 0) return 0;
-    const int splits = plan_splits(M, N, K);
-    return splits > 1 ? (int64_t)splits * M * N * 4 : 0;
+    if (K < GNK_BK || K % GNK_BK != 0 || N % 4 != 0) return 0;
+    const GemmPlan plan = plan_gemm(M, N, K, true, true, true);   // layout / alignment are re-checked at launch
+    return plan.splits > 1 ? (int64_t)plan.splits * M * N * 4 : 0;
 }
 
 extern "C" int gnk_scaled_mm_ws(const void *A, int a_dtype, const void *B, int b_dtype, void *C, int out_dtype,
