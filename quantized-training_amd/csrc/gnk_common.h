@@ -92,6 +92,20 @@ template <int DT> __device__ __forceinline__ float gnk_raw_to_f32(unsigned raw) 
     else return __uint_as_float(raw);
 }
 
+// Branch-free variants for a RUN-TIME dtype (bf16 / fp16 / fp32): two 2-byte loads -- the upper half of an fp32 element,
+// or the same 2 bytes again for the 16-bit types (never past the element) -- and a select at conversion time.  Used
+// where a load and its conversion sit in different loop iterations: uniform branches there produced control flow that
+// hipcc 7.2 miscompiled under amdgpu_waves_per_eu (the fp32 arm skipped half of the conversions).
+__device__ __forceinline__ unsigned gnk_load_raw_rt(const void *p, int dt, int64_t i) {
+    const int w = dt == GNK_F32 ? 2 : 1;
+    const unsigned short *h = (const unsigned short *)p + i * w;
+    return (unsigned)h[0] | ((unsigned)h[w - 1] << 16);
+}
+__device__ __forceinline__ float gnk_raw_to_f32_rt(unsigned raw, int dt) {
+    const float f32 = __uint_as_float(raw), bf = __uint_as_float(raw << 16), hf = gnk_f16_to_f32((unsigned short)(raw & 0xffffu));
+    return dt == GNK_F32 ? f32 : dt == GNK_F16 ? hf : bf;
+}
+
 __device__ __forceinline__ float gnk_load_scalar_rt(const void *p, int dt, int64_t i) {
     if (dt == GNK_BF16) return gnk_bf16_to_f32(((const unsigned short *)p)[i]);
     if (dt == GNK_F16) return gnk_f16_to_f32(((const unsigned short *)p)[i]);

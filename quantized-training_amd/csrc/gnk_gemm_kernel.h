@@ -239,14 +239,13 @@ template <int BM, int BN, int NT, int EPI> struct ScalePrefetch {
             const int64_t last = row ? p.M - 1 : p.N - 1;
             idx = idx < last ? idx : last;
             if (!row && p.col_scalar) idx = 0;
-            const void *src = row ? p.s0 : p.s1;
-            raw = p.scale_dtype == GNK_F32 ? ((const unsigned *)src)[idx] : (unsigned)((const unsigned short *)src)[idx];
+            raw = gnk_load_raw_rt(row ? p.s0 : p.s1, p.scale_dtype, idx);
         }
     }
     // call once the load has certainly landed (after the K loop) and before a workgroup barrier that precedes the epilogue
     __device__ __forceinline__ void park(const GemmParams &p, char *lds) const {
         if constexpr (EPI == EPI_ROWCOL) {
-            const float v = p.scale_dtype == GNK_BF16 ? gnk_raw_to_f32<GNK_BF16>(raw) : p.scale_dtype == GNK_F16 ? gnk_raw_to_f32<GNK_F16>(raw) : gnk_raw_to_f32<GNK_F32>(raw);
+            const float v = gnk_raw_to_f32_rt(raw, p.scale_dtype);
             *(GNK_LDS float *)(GNK_LDS char *)(lds + 4 * threadIdx.x) = v;
         }
     }
@@ -443,40 +442,35 @@ template <class Cfg> struct TileScaleIdx {
         astep = (int)p.ssak;
         bstep = (int)p.ssbk;
     }
-    template <int SDT> __device__ __forceinline__ void load_raw_t(const GemmParams &p, int t, unsigned (&ra)[MT], unsigned (&rb)[NTL]) const {
-        const int at = t * astep, bt = t * bstep;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) ra[i] = gnk_load_raw<SDT>(p.s0, aoff[i] + at);
-#pragma unroll
-        for (int j = 0; j < NTL; ++j) rb[j] = gnk_load_raw<SDT>(p.s1, boff[j] + bt);
-    }
+    // one load per scale (these loads share the vector-memory queue with the LDS-DMA stream: doubling them cost 10-40 %);
+    // the width is a two-armed uniform branch, the conversion (convert) is branch-free
     __device__ __forceinline__ void load_raw(const GemmParams &p, int t, unsigned (&ra)[MT], unsigned (&rb)[NTL]) const {
-        if (p.scale_dtype == GNK_F32) load_raw_t<GNK_F32>(p, t, ra, rb);
-        else load_raw_t<GNK_BF16>(p, t, ra, rb);   // bf16 and fp16 are both 2-byte loads
-    }
-    static __device__ __forceinline__ void convert(const GemmParams &p, const unsigned (&ra)[MT], const unsigned (&rb)[NTL], float (&sav)[MT], float (&sbv)[NTL]) {
-        if (p.scale_dtype == GNK_BF16) {
+        const int at = t * astep, bt = t * bstep;
+        if (p.scale_dtype == GNK_F32) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) sav[i] = gnk_raw_to_f32<GNK_BF16>(ra[i]);
+            for (int i = 0; i < MT; ++i) ra[i] = gnk_load_raw<GNK_F32>(p.s0, aoff[i] + at);
 #pragma unroll
-            for (int j = 0; j < NTL; ++j) sbv[j] = gnk_raw_to_f32<GNK_BF16>(rb[j]);
-        } else if (p.scale_dtype == GNK_F16) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i) sav[i] = gnk_raw_to_f32<GNK_F16>(ra[i]);
-#pragma unroll
-            for (int j = 0; j < NTL; ++j) sbv[j] = gnk_raw_to_f32<GNK_F16>(rb[j]);
+            for (int j = 0; j < NTL; ++j) rb[j] = gnk_load_raw<GNK_F32>(p.s1, boff[j] + bt);
         } else {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) sav[i] = gnk_raw_to_f32<GNK_F32>(ra[i]);
+            for (int i = 0; i < MT; ++i) ra[i] = gnk_load_raw<GNK_BF16>(p.s0, aoff[i] + at);
 #pragma unroll
-            for (int j = 0; j < NTL; ++j) sbv[j] = gnk_raw_to_f32<GNK_F32>(rb[j]);
+            for (int j = 0; j < NTL; ++j) rb[j] = gnk_load_raw<GNK_BF16>(p.s1, boff[j] + bt);
         }
+    }
+    static __device__ __forceinline__ void convert(const GemmParams &p, const unsigned (&ra)[MT], const unsigned (&rb)[NTL], float (&sav)[MT], float (&sbv)[NTL]) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) sav[i] = gnk_raw_to_f32_rt(ra[i], p.scale_dtype);
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) sbv[j] = gnk_raw_to_f32_rt(rb[j], p.scale_dtype);
     }
 };
 
 // ------------------------------------------------------------------------------ the kernel
+// amdgpu_waves_per_eu(2): the two-buffer kernels are designed for two workgroups per CU (64 KiB of LDS each), i.e. a
+// 256-register budget (VGPRs + AGPRs).  Without the hint the int8 tile-scaled instances took 264 and ran at half occupancy.
 template <class Cfg>
-__global__ void __launch_bounds__(Cfg::NT) gemm_kernel(const GemmParams p_in) {
+__global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cfg::NT == 256 ? 2 : 1))) gemm_kernel(const GemmParams p_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MT = Cfg::MT, NTL = Cfg::NTL;
     typedef typename AccT<Cfg::OP>::type acc_t;
