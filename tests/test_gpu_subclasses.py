@@ -89,3 +89,23 @@ def test_int8_linear_weight_dynamic_activation_on_gpu():
     opt = torch.optim.AdamW(lin.parameters(), lr=1e-2, foreach=False)
     opt.step()                                   # SR re-quantization through the HIP kernel
     assert lin.weight.int_data.dtype is torch.int8
+
+
+def test_train_bench_int8_mixed_precision_step_runs_on_the_gpu():
+    """End to end: transformers Llama (tiny) -> convert_mixed_precision -> gn_kernels ops -> HIP kernels -> AdamW, through
+    the harness the tok/s numbers come from; the INT8 loss must track the bf16 loss of the same seed."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    losses = {}
+    for q in ("none", "mixed_precision"):
+        r = subprocess.run([sys.executable, str(root / "train_bench.py"), "--model", "tiny", "--quantize", q, "--batch_size", "2", "--seq_len", "256",
+                            "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert out["value"] > 0
+        losses[q] = out["loss_first_last"]
+    assert abs(losses["none"][0] - losses["mixed_precision"][0]) < 0.02 and abs(losses["none"][1] - losses["mixed_precision"][1]) < 0.05

@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--weight_decay", type=float, default=1e-2)
     ap.add_argument("--activation_checkpointing", action="store_true")
     ap.add_argument("--device", default="cuda")
+    ap.add_argument("--gnk_debug_flags", type=int, default=0, help="A/B timing switches of libgnk_hip.so (gnk_set_debug_flags)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -83,6 +84,10 @@ def main():
     model = build_model(args.model, args.seq_len, dev)
     if args.activation_checkpointing:
         model.gradient_checkpointing_enable()
+    if args.gnk_debug_flags:
+        from gn_kernels import _cabi
+
+        _cabi.load().gnk_set_debug_flags(args.gnk_debug_flags)
     if args.quantize == "mixed_precision":
         from subclasses import convert_mixed_precision
 
