@@ -78,6 +78,35 @@ def time_kernel(fn, iters=30, warm=5):
     return sum(ts) / len(ts), ts[len(ts) // 2]
 
 
+def time_kernel_graph(fn, per_graph=20, replays=6):
+    """Average launch duration in ms with the Python / ctypes launch path taken out: `per_graph` calls are captured into a
+    HIP graph once and the graph is replayed (the reference's do_bench sees ~3 us CUDA launches; our op costs ~13 us of
+    host time per call, which would otherwise be what the 1024 / 2048 sizes measure)."""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(per_graph):
+                fn()
+    torch.cuda.current_stream().wait_stream(side)
+    g.replay()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(replays):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        g.replay()
+        e.record()
+        torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e) / per_graph)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
 def cpu_baseline(S=4096, budget_s=12.0):
     """The reference's CPU path (benchmark_mm.py:41, uncompiled): torch._int_mm + fp32 scale + cast, on
     the same 4096^3 A@B.T problem.  Imported from oracle/ -- the checker, timed as a baseline only."""
@@ -185,13 +214,20 @@ def main():
             for (d, l), a in cases.items():
                 avg, _ = time_kernel(lambda a=a: gn_kernels.scaled_mm(*a), iters=20)
                 detail[f"{d} {l} {S}"] = round(2 * S ** 3 / (avg * 1e-3) * 1e-12, 1)
+            graph = {}
             for s in (1024, 2048):
                 small = make_inputs(s, dev)
                 for d in ("int8", "fp8"):
                     for l in LAYOUTS:
                         avg, _ = time_kernel(lambda a=small[(d, l)]: gn_kernels.scaled_mm(*a), iters=20)
                         detail[f"{d} {l} {s}"] = round(2 * s ** 3 / (avg * 1e-3) * 1e-12, 1)
+                        try:
+                            med = time_kernel_graph(lambda a=small[(d, l)]: gn_kernels.scaled_mm(*a))
+                            graph[f"{d} {l} {s}"] = round(2 * s ** 3 / (med * 1e-3) * 1e-12, 1)
+                        except Exception as exc:   # graph capture is a measurement aid, never a reason to lose the bench line
+                            graph[f"{d} {l} {s}"] = f"capture failed: {type(exc).__name__}"
             out["detail_tops"] = detail
+            out["detail_tops_hipgraph_replay"] = graph
             # quantize pass: algorithmic bytes = 3*R*C + 2*R (read bf16 once, write int8 + bf16 scales)
             from subclasses import quantize_int8
 
@@ -205,6 +241,12 @@ def main():
                     nbytes = 3 * R * C + 2 * (R if dim == 1 else C)
                     gbs = nbytes / (avg * 1e-3) * 1e-9
                     q[f"{R}x{C} {name}"] = {"GB/s": round(gbs, 1), "frac_of_8TBs": round(gbs / PEAK_HBM_GBS, 4), "us": round(avg * 1e3, 2)}
+                    try:   # the same pass replayed from a HIP graph: kernel time without the Python launch path
+                        med = time_kernel_graph(lambda dim=dim: quantize_int8(x, dim=dim), per_graph=10)
+                        q[f"{R}x{C} {name}"].update({"hipgraph_us": round(med * 1e3, 2), "hipgraph_GB/s": round(nbytes / (med * 1e-3) * 1e-9, 1),
+                                                     "hipgraph_frac_of_8TBs": round(nbytes / (med * 1e-3) * 1e-9 / PEAK_HBM_GBS, 4)})
+                    except Exception as exc:
+                        q[f"{R}x{C} {name}"]["hipgraph_us"] = f"capture failed: {type(exc).__name__}"
                 del x
             out["detail_quantize_bf16"] = q
         if world == 1 and not args.no_cpu:

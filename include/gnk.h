@@ -142,10 +142,10 @@ int gnk_fp8_mm(const void *A, int a_dtype, const void *B, int b_dtype, void *C, 
 int gnk_set_gemm_variant(int variant);
 
 /*
- * Timing-ablation hook (no reference counterpart; results are WRONG while flags != 0): bit 0 drops the
- * main loop's LDS-DMA loads, bit 1 the MFMAs, bit 2 the LDS fragment reads of the 8-phase 256 x 256 kernel
- * (variant 4; the other kernels ignore the flags).
- * Used by tools/ablate.py to attribute kernel time.  Returns the previous flags.
+ * Timing-ablation hook (no reference counterpart; results are WRONG while bits 0-3 are set).  Bits 0-3 act on the
+ * 8-phase 256 x 256 GEMM kernel only (variant 4): 1 drops the main loop's LDS-DMA loads, 2 the MFMAs, 4 the LDS fragment
+ * reads, 8 the whole epilogue.  Bit 4 (16) makes the quantize kernels use plain instead of nontemporal stores (results
+ * unchanged).  Used by tools/ablate*.py and train_bench.py --gnk_debug_flags to attribute time.  Returns the previous flags.
  */
 int gnk_set_debug_flags(int flags);
 

@@ -318,8 +318,8 @@ int launch_rowwise(const void *x, int8_t *q, void *scale, int64_t R, int64_t C, 
     const int64_t want = (R + 3) / 4;
     const dim3 grid((unsigned)(want < max_blocks ? want : max_blocks)), block(256);
     // Nontemporal (streaming) stores for the int8 copy: 12.1 -> 9.5 us at 4096^2 bf16 (the copy is read back by the GEMM
-    // through L2 anyway).  Debug flag 8 restores plain stores for A/B timing.
-    const bool nt = !(gnk_debug_flags_get() & 8);
+    // through L2 anyway).  Debug flag 16 restores plain stores for A/B timing.
+    const bool nt = !(gnk_debug_flags_get() & 16);
 #define GNK_ROW(NCH)                                                                                              \
     do {                                                                                                          \
         if (nt) hipLaunchKernelGGL((quant_rowwise_kernel<DT, NCH, SR, true>), grid, block, 0, st, (const char *)x, q, scale, R, C, sxr_bytes, sqr, eps, seed, offset); \
@@ -345,7 +345,7 @@ int launch_colwise(const void *x, int8_t *q, void *scale, int64_t P, int64_t Q, 
     if (hipMemsetAsync(ws, 0, (size_t)Q * 4, st) != hipSuccess) return gnk_fail(GNK_ERR_LAUNCH, "quantize_int8: memset of workspace failed");
     const int64_t gx = (Q + 32 * VEC - 1) / (32 * VEC);
     const dim3 block(256);
-    const bool nt = !(gnk_debug_flags_get() & 8);
+    const bool nt = !(gnk_debug_flags_get() & 16);
     if (gx * ((P + 127) / 128) * 2 >= (int64_t)gnk_num_cus()) {   // measured: 128-row slabs win down to 1 block per CU (4096^2, 8192 x 1024)
         const dim3 grid((unsigned)gx, (unsigned)((P + 127) / 128));
         hipLaunchKernelGGL((col_absmax_kernel<DT, 128>), grid, block, 0, st, (const char *)x, ws, P, Q, ld_bytes);
