@@ -37,8 +37,8 @@ cs = torch.randn(1, S, device="cuda").div(128).bfloat16()
 names = {0: "full", 1: "no DMA", 2: "no MFMA", 4: "no LDS reads", 3: "no DMA, no MFMA", 5: "no DMA, no reads (MFMA + barriers)",
          6: "no MFMA, no reads (DMA + barriers)", 7: "barriers only"}
 for tag, (a, b) in {"int8 NT": (A, Bt.T), "int8 NN": (A, Bt), "int8 TN": (A.T, Bt), "fp8 NT": (A8, B8t.T)}.items():
-    for v in (0, 3):
-        if v == 3 and not tag.startswith("int8"):
+    for v in (4, 3):   # 4 = the 8-phase kernel, the only one that carries the ablation flags (int8 only); 3 = first kernel
+        if not tag.startswith("int8"):
             continue
         L.gnk_set_gemm_variant(v)
         for flags, nm in names.items():
