@@ -233,6 +233,26 @@ def test_split_k_is_bit_identical(shape, layout):
             L.gnk_set_gemm_variant(-1)
 
 
+def test_degenerate_shapes():
+    """K = 0 (empty reduction: all zeros), a single row / column, and a row-scaled product whose scale is zero."""
+    A0 = torch.zeros(5, 0, dtype=torch.int8, device=DEV)
+    B0 = torch.zeros(0, 7, dtype=torch.int8, device=DEV)
+    assert torch.equal(gn_kernels.int8_mm(A0, B0).cpu(), torch.zeros(5, 7, dtype=torch.int32))
+    rs, cs = torch.ones(5, 1, device=DEV).bfloat16(), torch.ones(1, 7, device=DEV).bfloat16()
+    assert torch.equal(gn_kernels.scaled_mm(A0, B0, rs, cs).float().cpu(), torch.zeros(5, 7))
+    g = torch.Generator().manual_seed(3)
+    A = torch.randint(-128, 128, (1, 256), dtype=torch.int8, generator=g)
+    B = to_layout(torch.randint(-128, 128, (256, 1), dtype=torch.int8, generator=g), True)
+    rs1, cs1 = torch.randn(1, 1, generator=g).bfloat16(), torch.randn(1, 1, generator=g).bfloat16()
+    assert bits_equal(gn_kernels.scaled_mm(A.to(DEV), dev_layout(B, True), rs1.to(DEV), cs1.to(DEV)), oracle.scaled_mm(A, B, rs1, cs1))
+    A = torch.randint(-128, 128, (256, 128), dtype=torch.int8, generator=g)
+    B = to_layout(torch.randint(-128, 128, (128, 256), dtype=torch.int8, generator=g), True)
+    rz = torch.zeros(256, 1).bfloat16()
+    cz = torch.randn(1, 256, generator=g).bfloat16()
+    out = gn_kernels.scaled_mm(A.to(DEV), dev_layout(B, True), rz.to(DEV), cz.to(DEV))
+    assert bits_equal(out, oracle.scaled_mm(A, B, rz, cz))     # signed zeros included
+
+
 def test_errors_surface_as_exceptions():
     A = torch.zeros(4, 8, dtype=torch.int8, device=DEV)
     with pytest.raises(RuntimeError):
