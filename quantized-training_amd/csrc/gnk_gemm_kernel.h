@@ -288,13 +288,18 @@ template <class Cfg> struct EpiScales {
             else load_t<GNK_F32>(p, mrow, ncol);
         }
     }
-    template <class AccT_>
+    // ORDER 0: (acc * row) * col (triton_mm.py:207-212); 1: (acc * col) * row (the CUTLASS-named ops); -1: p.order at run time.
+    // The staged epilogues resolve it once per kernel (a per-element select computes both products: 4 multiplies and a
+    // v_cndmask per output where 2 multiplies do).
+    template <int ORDER = -1, class AccT_>
     __device__ __forceinline__ float value(const GemmParams &p, const AccT_ &acc, const v4f *accf, int i, int j, int r) const {
         if constexpr (Cfg::EPI == EPI_TILE) return (*accf)[r];
         float a;
         if constexpr (Cfg::OP == OP_I8) a = (float)acc[r];   // v_cvt_f32_i32: RNE
         else a = acc[r];
         if constexpr (Cfg::EPI == EPI_PLAIN) return a;
+        if constexpr (ORDER == 0) return __fmul_rn(__fmul_rn(a, rs[i]), cs[j][r]);
+        if constexpr (ORDER == 1) return __fmul_rn(__fmul_rn(a, cs[j][r]), rs[i]);
         return p.order == 0 ? __fmul_rn(__fmul_rn(a, rs[i]), cs[j][r]) : __fmul_rn(__fmul_rn(a, cs[j][r]), rs[i]);
     }
 };
@@ -343,7 +348,7 @@ __device__ __forceinline__ void epilogue(const GemmParams &p, typename AccT<Cfg:
 // 32 B per row and instruction measured 1.6 TB/s; whole-line stores run at the HBM write rate.
 // LDS image per wave: [WTM rows][128 B], 16-byte chunk c of row m kept at c ^ (m & 7) (conflict-free
 // ds_read_b128, 2-way ds_write_b64).
-template <class Cfg, int OUT>
+template <class Cfg, int OUT, int ORDER = -1>
 __device__ __forceinline__ void epilogue_lds(const GemmParams &p, typename AccT<Cfg::OP>::type (&acc)[Cfg::MT][Cfg::NTL],
                                              v4f (*accf)[Cfg::EPI == EPI_TILE ? Cfg::NTL : 1], char *smem, int wave, int lane,
                                              int64_t mwave, int64_t nwave, const float *lsc = nullptr, int mlw = 0, int nlw = 0) {
@@ -353,6 +358,14 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams &p, typename AccT<
     const int g = lane >> 4, ml = lane & 15;
     EpiScales<Cfg> sc;
     sc.load(p, mwave + ml, nwave + 4 * g, lsc, mlw + ml, nlw + 4 * g);
+    // store side: lane -> (row it * 8 + (lane >> 3), 16-byte chunk lane & 7); one 64-bit address per lane, advanced by a
+    // wave-uniform 8 * N elements per store (per-store m * N + n in 64 bits cost ~10 VALU each)
+    const int srow = lane >> 3, sc8 = lane & 7;
+    const int64_t rows_left64 = p.M - mwave - srow;
+    const int rows_left = rows_left64 > Cfg::WTM ? Cfg::WTM : (int)rows_left64;   // store row it * 8 is valid iff it * 8 < rows_left
+    const bool col_ok = nwave + 8 * sc8 < p.N;
+    unsigned short *const cbase = (unsigned short *)p.C + (mwave + srow) * p.N + nwave + 8 * sc8;
+    const int64_t cstep = 8 * p.N;
     // row block i (16 rows) is complete after its NTL tiles: its two 8-row store groups go out at once, so global
     // stores overlap the conversion of the following row blocks (same wave wrote and reads its slice: in order)
 #pragma unroll
@@ -361,7 +374,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams &p, typename AccT<
         for (int j = 0; j < Cfg::NTL; ++j) {
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = sc.value(p, acc[i][j], Cfg::EPI == EPI_TILE ? &accf[i][j] : nullptr, i, j, r);
+            for (int r = 0; r < 4; ++r) v[r] = sc.template value<ORDER>(p, acc[i][j], Cfg::EPI == EPI_TILE ? &accf[i][j] : nullptr, i, j, r);
             v2i o;
             if constexpr (OUT == GNK_BF16) {
                 o[0] = (int)gnk_pack2_bf16(v[0], v[1]);
@@ -375,10 +388,9 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams &p, typename AccT<
         }
 #pragma unroll
         for (int it = 2 * i; it < 2 * i + 2; ++it) {
-            const int row = it * 8 + (lane >> 3), c = lane & 7;
-            const v4i d = *(const GNK_LDS v4i *)(const GNK_LDS char *)(region + row * 128 + ((c ^ (row & 7)) << 4));
-            const int64_t m = mwave + row, n = nwave + 8 * c;
-            if (m < p.M && n < p.N) *(v4i *)((unsigned short *)p.C + m * p.N + n) = d;
+            const int row = it * 8 + srow;
+            const v4i d = *(const GNK_LDS v4i *)(const GNK_LDS char *)(region + row * 128 + ((sc8 ^ (row & 7)) << 4));
+            if (col_ok && it * 8 < rows_left) *(v4i *)(cbase + it * cstep) = d;
         }
     }
 }
@@ -400,11 +412,17 @@ __device__ __forceinline__ void run_epilogue(const GemmParams &p, typename AccT<
     } else {
         const bool lds_ok = (p.N % 8 == 0) && aligned16;
         if (p.out_dtype == GNK_BF16) {
-            if (lds_ok) epilogue_lds<Cfg, GNK_BF16>(p, acc, accf, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
+            if (lds_ok) {
+                if (Cfg::EPI != EPI_ROWCOL || p.order == 0) epilogue_lds<Cfg, GNK_BF16, 0>(p, acc, accf, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
+                else epilogue_lds<Cfg, GNK_BF16, 1>(p, acc, accf, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
+            }
             else if (vec_ok) epilogue<Cfg, GNK_BF16, true>(p, acc, accf, mrow, ncol, lsc, mloc, nloc);
             else epilogue<Cfg, GNK_BF16, false>(p, acc, accf, mrow, ncol, lsc, mloc, nloc);
         } else if (p.out_dtype == GNK_F16) {
-            if (lds_ok) epilogue_lds<Cfg, GNK_F16>(p, acc, accf, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
+            if (lds_ok) {
+                if (Cfg::EPI != EPI_ROWCOL || p.order == 0) epilogue_lds<Cfg, GNK_F16, 0>(p, acc, accf, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
+                else epilogue_lds<Cfg, GNK_F16, 1>(p, acc, accf, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
+            }
             else if (vec_ok) epilogue<Cfg, GNK_F16, true>(p, acc, accf, mrow, ncol, lsc, mloc, nloc);
             else epilogue<Cfg, GNK_F16, false>(p, acc, accf, mrow, ncol, lsc, mloc, nloc);
         } else {

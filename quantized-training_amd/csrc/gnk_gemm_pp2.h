@@ -188,15 +188,17 @@ template <class Cfg> struct PP2F8 {
 
     // ------------------------------------------------------------------ epilogue (32 x 32 tile maps)
     // lane: m = mwave + 32 i + (lane & 31);  n = nwave + 32 j + 8 g + 4 h + r  with reg = 4 g + r, h = lane >> 5
-    static __device__ __forceinline__ float value(const GemmParams &p, const acc_t &a, int reg, float rs, float cs) {
+    template <int ORDER> static __device__ __forceinline__ float value(const GemmParams &p, const acc_t &a, int reg, float rs, float cs) {
         float x;
         if constexpr (Cfg::OP == OP_I8) x = (float)a[reg];   // v_cvt_f32_i32: RNE
         else x = a[reg];
         if constexpr (Cfg::EPI == EPI_PLAIN) return x;
+        if constexpr (ORDER == 0) return __fmul_rn(__fmul_rn(x, rs), cs);
+        if constexpr (ORDER == 1) return __fmul_rn(__fmul_rn(x, cs), rs);
         return p.order == 0 ? __fmul_rn(__fmul_rn(x, rs), cs) : __fmul_rn(__fmul_rn(x, cs), rs);
     }
 
-    template <int OUT, int MODE>   // MODE 0: LDS-staged 16-byte stores (2-byte outputs); 1: direct vector; 2: direct scalar
+    template <int OUT, int MODE, int ORDER = -1>   // ORDER: multiply order resolved at compile time (see EpiScales::value)   // MODE 0: LDS-staged 16-byte stores (2-byte outputs); 1: direct vector; 2: direct scalar
     static __device__ __forceinline__ void epilogue(const GemmParams &p, acc_t (&acc)[4][2], char *smem, int wave, int lane, int64_t mwave, int64_t nwave,
                                                     const float *lsc, int mlw, int nlw) {
         float rs[4], cs[2][4][4];
@@ -213,6 +215,13 @@ template <class Cfg> struct PP2F8 {
         }
         const int ml = lane & 31, h = lane >> 5;
         char *const region = smem + wave * (128 * 128);   // this wave's 128 rows x 128 B result slice
+        // store side of the staged form: see epilogue_lds (one 64-bit address per lane, wave-uniform step)
+        const int srow = lane >> 3, sc8 = lane & 7;
+        const int64_t rows_left64 = p.M - mwave - srow;
+        const int rows_left = rows_left64 > 128 ? 128 : (int)rows_left64;
+        const bool col_ok = nwave + 8 * sc8 < p.N;
+        unsigned short *const cbase = (unsigned short *)p.C + (mwave + srow) * p.N + nwave + 8 * sc8;
+        const int64_t cstep = 8 * p.N;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -223,7 +232,7 @@ template <class Cfg> struct PP2F8 {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         if constexpr (OUT == GNK_I32) v[r] = __int_as_float(acc[i][j][4 * g + r]);
-                        else v[r] = value(p, acc[i][j], 4 * g + r, rs[i], cs[j][g][r]);
+                        else v[r] = value<ORDER>(p, acc[i][j], 4 * g + r, rs[i], cs[j][g][r]);
                     }
                     if constexpr (MODE == 0) {
                         v2i o;
@@ -243,10 +252,9 @@ template <class Cfg> struct PP2F8 {
             if constexpr (MODE == 0) {   // rows 32 i .. 32 i + 31 are complete: store them while the next row block converts
 #pragma unroll
                 for (int it = 4 * i; it < 4 * i + 4; ++it) {
-                    const int row = it * 8 + (lane >> 3), c = lane & 7;
-                    const v4i d = *(const GNK_LDS v4i *)(const GNK_LDS char *)(region + row * 128 + ((c ^ (row & 7)) << 4));
-                    const int64_t m = mwave + row, n = nwave + 8 * c;
-                    if (m < p.M && n < p.N) *(v4i *)((unsigned short *)p.C + m * p.N + n) = d;
+                    const int row = it * 8 + srow;
+                    const v4i d = *(const GNK_LDS v4i *)(const GNK_LDS char *)(region + row * 128 + ((sc8 ^ (row & 7)) << 4));
+                    if (col_ok && it * 8 < rows_left) *(v4i *)(cbase + it * cstep) = d;
                 }
             }
         }
@@ -259,11 +267,17 @@ template <class Cfg> struct PP2F8 {
             if (vec_ok) epilogue<GNK_I32, 1>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
             else epilogue<GNK_I32, 2>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
         } else if (p.out_dtype == GNK_BF16) {
-            if (lds_ok) epilogue<GNK_BF16, 0>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
+            if (lds_ok) {
+                if (Cfg::EPI != EPI_ROWCOL || p.order == 0) epilogue<GNK_BF16, 0, 0>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
+                else epilogue<GNK_BF16, 0, 1>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
+            }
             else if (vec_ok) epilogue<GNK_BF16, 1>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
             else epilogue<GNK_BF16, 2>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
         } else if (p.out_dtype == GNK_F16) {
-            if (lds_ok) epilogue<GNK_F16, 0>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
+            if (lds_ok) {
+                if (Cfg::EPI != EPI_ROWCOL || p.order == 0) epilogue<GNK_F16, 0, 0>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
+                else epilogue<GNK_F16, 0, 1>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
+            }
             else if (vec_ok) epilogue<GNK_F16, 1>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
             else epilogue<GNK_F16, 2>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
         } else {
