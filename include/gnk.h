@@ -71,6 +71,30 @@ int gnk_quantize_int8(const void *x, int x_dtype, int64_t R, int64_t C, int64_t 
 int64_t gnk_quantize_int8_workspace_bytes(int64_t R, int64_t C, int64_t sxr, int64_t sxc);
 
 /*
+ * Fused dual-direction quantization.  The reference quantizes every X, W and dY of a
+ * mixed-precision Linear along BOTH dims each step (subclasses/mixed_precision.py:100-108 called from :154, :178,
+ * :186) and notes the missed fusion itself (subclasses/int8.py:155-156); each call there is an independent
+ * quantize_int8 (int8.py:12-26).  Same arithmetic, fewer HBM reads:
+ *
+ * gnk_quantize_int8_rowwise_colmax == gnk_quantize_int8 along the contiguous dim (rows of C contiguous elements,
+ *   row stride sxr, 16-byte aligned) that ALSO writes colmax[c] = amax_r |x[r,c]| (fp32, C values) from the same read.
+ *   Rows of at most 6144 16-bit / 3072 fp32 elements; workspace of ..._workspace_bytes() (0 = shape not supported:
+ *   use gnk_quantize_int8), 16-byte aligned, holds one partial row of maxima per workgroup (no global atomics).
+ * gnk_quantize_int8_colwise_given_absmax == gnk_quantize_int8 along the STRIDED dim of a row-major (P, Q) matrix
+ *   (leading dimension ld; q with ldq) for a caller that already holds absmax[q] = amax_p |x[p,q]| (fp32): scale[q]
+ *   = absmax[q] / 127 stored as x_dtype, q[p,q] = clip(round(x[p,q] / max(scale[q], eps))): one read instead of two.
+ *   Stochastic rounding indexes Philox by q * P + p, as gnk_quantize_int8 does for the (Q, P) logical view.
+ */
+int64_t gnk_quantize_int8_rowwise_colmax_workspace_bytes(int x_dtype, int64_t R, int64_t C);
+int gnk_quantize_int8_rowwise_colmax(const void *x, int x_dtype, int64_t R, int64_t C, int64_t sxr,
+                                     int8_t *q, int64_t sqr, void *scale, float *colmax, float eps,
+                                     int sr, uint64_t seed, uint64_t offset,
+                                     void *workspace, int64_t workspace_bytes, void *stream);
+int gnk_quantize_int8_colwise_given_absmax(const void *x, int x_dtype, int64_t P, int64_t Q, int64_t ld,
+                                           int8_t *q, int64_t ldq, void *scale, const float *absmax, float eps,
+                                           int sr, uint64_t seed, uint64_t offset, void *stream);
+
+/*
  * C(int32, M x N) = A(int8, M x K) @ B(int8, K x N), exact.
  * Replaces: kernels/gn_kernels/triton_mm.py:112-143 (int8_mm -> _triton_mm -> _matmul_kernel
  * :53-109 with ACC_DTYPE=int32).  Any strides; the three layouts of benchmark_mm.py:33-34,91-96

@@ -176,6 +176,147 @@ quant_rowwise_long_kernel(const char *__restrict__ x, int8_t *__restrict__ q, vo
 }
 
 // ------------------------------------------------------------------------------------------
+// fused: row-wise quantize + per-column absmax of the SAME read.
+// subclasses/mixed_precision.py quantizes every X, W and dY twice per step, once along each dim
+// (:100-108 with :154,:178,:186).  The column-wise pass needs the column absmax before it can
+// quantize anything, i.e. two reads; this kernel collects it while the row-wise pass has the row
+// in registers anyway, so the column-wise quantization later costs ONE more read instead of two.
+//   * a lane owns the same columns in every row it sees (chunk i * 64 + lane), so the running
+//     column maxima are per-lane registers: packed |x| bit patterns for 16-bit inputs
+//     (v_pk_max_u16 on raw & 0x7fff7fff: non-negative floats order like their bits), floats for f32;
+//   * no global atomics (every block hitting the same C words serialises in L2: measured 5-20x
+//     slower): the block's 8 waves merge through LDS (ds_max_u32 per column) and write ONE partial
+//     row; a second, tiny kernel reduces the <= 2 * CUs partial rows to fp32 column maxima.
+// ------------------------------------------------------------------------------------------
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
+}
+
+template <int DT, int NCH, bool SR, bool NT>
+__global__ void __launch_bounds__(512)
+quant_rowwise_colmax_kernel(const char *__restrict__ x, int8_t *__restrict__ q, void *__restrict__ scale,
+                            unsigned *__restrict__ partial, int64_t R, int64_t C, int64_t sxr_bytes, int64_t sqr, float eps,
+                            unsigned long long seed, unsigned long long offset) {
+    constexpr int VEC = ElemTraits<DT>::VEC;
+    extern __shared__ unsigned colmax_lds[];                 // C words: this block's column maxima as fp32 bit patterns
+    const int lane = threadIdx.x & 63;
+    const int64_t nwaves = (int64_t)gridDim.x * 8;
+    int64_t r = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 6);
+    const int nchunks = (int)(C / VEC);
+    for (int c = threadIdx.x; c < (int)C; c += 512) colmax_lds[c] = 0u;
+
+    unsigned cm[NCH][4];                                     // 16-bit inputs: 2 columns per word; f32: fp32 bits, 1 column per word
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cm[i][j] = 0u;
+
+    v4i raw[NCH], nxt[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = i * 64 + lane;
+        nxt[i] = (v4i){0, 0, 0, 0};
+        if (r < R && ch < nchunks) nxt[i] = *(const v4i *)(x + r * sxr_bytes + (int64_t)ch * 16);
+    }
+    for (; r < R; r += nwaves) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) raw[i] = nxt[i];
+        const int64_t rn = r + nwaves;
+        if (rn < R) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int ch = i * 64 + lane;
+                if (ch < nchunks) nxt[i] = *(const v4i *)(x + rn * sxr_bytes + (int64_t)ch * 16);
+            }
+        }
+        float amax = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            float f[VEC];
+            unpack16<DT>(raw[i], f);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) amax = fmaxf(amax, fabsf(f[j]));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (DT == GNK_F32) cm[i][j] = __float_as_uint(fmaxf(__uint_as_float(cm[i][j]), fabsf(f[j])));
+                else cm[i][j] = pk_max_u16(cm[i][j], (unsigned)raw[i][j] & 0x7fff7fffu);
+            }
+        }
+        amax = wave_max(amax);
+        const float s = amax / 127.0f;
+        GnkDivisor dv;
+        dv.set(fmaxf(s, eps));
+        const bool fast = dv.ok();
+        if (lane == 0) gnk_store_scalar_rt(scale, DT, r, s);
+
+        int8_t *qrow = q + r * sqr;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = i * 64 + lane;
+            if (ch < nchunks)
+                quant_chunk<DT, SR, VEC, NT>(raw[i], dv, fast, qrow + (int64_t)ch * VEC, seed, offset,
+                                             (unsigned long long)(r * C + (int64_t)ch * VEC));
+        }
+    }
+
+    // merge the 8 waves' column maxima (non-negative fp32 bit patterns order like unsigned integers)
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = i * 64 + lane;
+        if (ch < nchunks) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (DT == GNK_F32) {
+                    if (cm[i][j]) atomicMax(&colmax_lds[ch * 4 + j], cm[i][j]);
+                } else {
+                    const unsigned lo = cm[i][j] & 0xffffu, hi = cm[i][j] >> 16;
+                    unsigned flo, fhi;
+                    if constexpr (DT == GNK_BF16) { flo = lo << 16; fhi = hi << 16; }
+                    else { flo = __float_as_uint(gnk_f16_to_f32((unsigned short)lo)); fhi = __float_as_uint(gnk_f16_to_f32((unsigned short)hi)); }
+                    if (flo) atomicMax(&colmax_lds[ch * 8 + 2 * j], flo);
+                    if (fhi) atomicMax(&colmax_lds[ch * 8 + 2 * j + 1], fhi);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    unsigned *prow = partial + (int64_t)blockIdx.x * C;
+    for (int c = threadIdx.x * 4; c < (int)C; c += 512 * 4)   // C % 4 == 0 (C % VEC == 0)
+        *(v4i *)(prow + c) = *(const v4i *)(colmax_lds + c);
+}
+
+// partial[G][C] (fp32 bit patterns) -> colmax[C].  64 columns x 16 row lanes per block, 8 independent loads in flight per
+// thread: the kernel is pure latency (a serial walk over 512 partial rows took 25 us; this takes ~3).
+__global__ void __launch_bounds__(1024) colmax_reduce_kernel(const unsigned *__restrict__ partial, unsigned *__restrict__ colmax, int64_t G, int64_t C) {
+    __shared__ unsigned red[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * 64 + tx;
+    unsigned m = 0u;
+    if (c < C) {
+        for (int64_t g0 = ty; g0 < G; g0 += 16 * 8) {
+            unsigned v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t g = g0 + 16 * u;
+                v[u] = g < G ? partial[g * C + c] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) m = v[u] > m ? v[u] : m;
+        }
+    }
+    red[ty][tx] = m;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+#pragma unroll
+        for (int i = 1; i < 16; ++i) m = red[i][tx] > m ? red[i][tx] : m;
+        colmax[c] = m;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // colwise: memory matrix [P][Q] (Q contiguous); logical rows are the Q columns, the reduction
 // runs over P.  Block = 32 column-lanes (VEC columns each) x 8 row-lanes over a PB-row slab.
 // ------------------------------------------------------------------------------------------
@@ -359,6 +500,51 @@ int launch_colwise(const void *x, int8_t *q, void *scale, int64_t P, int64_t Q, 
     return gnk_check_launch("quantize_int8 colwise");
 }
 
+inline int64_t rowcol_blocks(int64_t R) {
+    const int64_t want = (R + 7) / 8, cap = (int64_t)gnk_num_cus() * 2;
+    return want < cap ? want : cap;
+}
+
+template <int DT, bool SR>
+int launch_rowwise_colmax(const void *x, int8_t *q, void *scale, float *colmax, int64_t R, int64_t C, int64_t sxr, int64_t sqr, float eps,
+                          uint64_t seed, uint64_t offset, unsigned *partial, hipStream_t st) {
+    constexpr int VEC = ElemTraits<DT>::VEC;
+    const int64_t sxr_bytes = sxr * (16 / VEC);
+    const int64_t per_lane = (C / VEC + 63) / 64;
+    const int64_t G = rowcol_blocks(R);
+    const dim3 grid((unsigned)G), block(512);
+    const size_t lds = (size_t)C * 4;
+#define GNK_ROWCOL(NCH) hipLaunchKernelGGL((quant_rowwise_colmax_kernel<DT, NCH, SR, true>), grid, block, lds, st, (const char *)x, q, scale, partial, R, C, sxr_bytes, sqr, eps, seed, offset)
+    if (per_lane <= 1) GNK_ROWCOL(1);
+    else if (per_lane <= 2) GNK_ROWCOL(2);
+    else if (per_lane <= 4) GNK_ROWCOL(4);
+    else if (per_lane <= 8) GNK_ROWCOL(8);
+    else GNK_ROWCOL(12);   // row + prefetched row + column maxima = 3 x 4 x NCH registers: 12 chunks is what 256 VGPRs hold without spilling
+#undef GNK_ROWCOL
+    int rc = gnk_check_launch("quantize_int8 rowwise + column absmax");
+    if (rc) return rc;
+    hipLaunchKernelGGL(colmax_reduce_kernel, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, st, partial, (unsigned *)colmax, G, C);
+    return gnk_check_launch("quantize_int8 column absmax reduction");
+}
+
+// pass 2 of the strided reduction alone: the column absmax is given (fp32, e.g. from launch_rowwise_colmax)
+template <int DT, bool SR>
+int launch_colwise_given(const void *x, int8_t *q, void *scale, int64_t P, int64_t Q, int64_t ld, int64_t ldq, float eps,
+                         uint64_t seed, uint64_t offset, const unsigned *amax, hipStream_t st) {
+    constexpr int VEC = ElemTraits<DT>::VEC;
+    const int64_t ld_bytes = ld * (16 / VEC);
+    const int64_t gx = (Q + 32 * VEC - 1) / (32 * VEC);
+    const dim3 block(256);
+    if (gx * ((P + 127) / 128) * 2 >= (int64_t)gnk_num_cus()) {
+        const dim3 grid((unsigned)gx, (unsigned)((P + 127) / 128));
+        hipLaunchKernelGGL((col_quant_kernel<DT, SR, 128, true>), grid, block, 0, st, (const char *)x, q, scale, amax, P, Q, ld_bytes, ldq, eps, seed, offset);
+    } else {
+        const dim3 grid((unsigned)gx, (unsigned)((P + 31) / 32));
+        hipLaunchKernelGGL((col_quant_kernel<DT, SR, 32, false>), grid, block, 0, st, (const char *)x, q, scale, amax, P, Q, ld_bytes, ldq, eps, seed, offset);
+    }
+    return gnk_check_launch("quantize_int8 colwise (given absmax)");
+}
+
 inline bool aligned(const void *p, int a) { return ((uintptr_t)p % a) == 0; }
 
 }  // namespace
@@ -413,4 +599,56 @@ extern "C" int gnk_quantize_int8(const void *x, int x_dtype, int64_t R, int64_t 
         hipLaunchKernelGGL((quant_generic_kernel<false>), dim3(grid), dim3(256), 0, st, x, x_dtype, q, scale, R, C, sxr, sxc,
                            sqr, sqc, eps, seed, offset);
     return gnk_check_launch("quantize_int8 generic");
+}
+
+// ---- fused dual-direction entry points (include/gnk.h) ---------------------------------------------------------
+static bool rowcol_supported(int x_dtype, int64_t R, int64_t C) {
+    if (!gnk_is_float_dtype(x_dtype) || R <= 0 || C <= 0) return false;
+    const int vec = 16 / gnk_dtype_size(x_dtype);
+    return C % vec == 0 && (C / vec + 63) / 64 <= 12;   // rows of up to 6144 16-bit / 3072 fp32 elements; longer rows take the two separate passes
+}
+
+extern "C" int64_t gnk_quantize_int8_rowwise_colmax_workspace_bytes(int x_dtype, int64_t R, int64_t C) {
+    if (!rowcol_supported(x_dtype, R, C)) return 0;
+    return rowcol_blocks(R) * C * 4;
+}
+
+extern "C" int gnk_quantize_int8_rowwise_colmax(const void *x, int x_dtype, int64_t R, int64_t C, int64_t sxr, int8_t *q, int64_t sqr,
+                                                void *scale, float *colmax, float eps, int sr, uint64_t seed, uint64_t offset,
+                                                void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!rowcol_supported(x_dtype, R, C)) return gnk_fail(GNK_ERR_UNSUPPORTED, "quantize_int8_rowwise_colmax: shape (%lld, %lld) / dtype code %d has no fused kernel", (long long)R, (long long)C, x_dtype);
+    if (!x || !q || !scale || !colmax) return gnk_fail(GNK_ERR_BAD_ARG, "quantize_int8_rowwise_colmax: null pointer");
+    const int esz = gnk_dtype_size(x_dtype), vec = 16 / esz;
+    if (!(aligned(x, 16) && (sxr * esz) % 16 == 0 && aligned(q, vec) && sqr % vec == 0 && sxr >= C && sqr >= C && aligned(colmax, 4)))
+        return gnk_fail(GNK_ERR_UNSUPPORTED, "quantize_int8_rowwise_colmax: rows must be contiguous, 16-byte aligned");
+    int rc = gnk_init();
+    if (rc) return rc;
+    const int64_t need = rowcol_blocks(R) * C * 4;
+    if (!workspace || workspace_bytes < need || !aligned(workspace, 16))
+        return gnk_fail(GNK_ERR_WORKSPACE, "quantize_int8_rowwise_colmax: needs a 16-byte aligned workspace of %lld bytes", (long long)need);
+    hipStream_t st = (hipStream_t)stream;
+#define GNK_DISPATCH2(FN, ...)                                                         \
+    do {                                                                              \
+        if (x_dtype == GNK_BF16) return sr ? FN<GNK_BF16, true>(__VA_ARGS__) : FN<GNK_BF16, false>(__VA_ARGS__); \
+        if (x_dtype == GNK_F16) return sr ? FN<GNK_F16, true>(__VA_ARGS__) : FN<GNK_F16, false>(__VA_ARGS__);    \
+        return sr ? FN<GNK_F32, true>(__VA_ARGS__) : FN<GNK_F32, false>(__VA_ARGS__); \
+    } while (0)
+    GNK_DISPATCH2(launch_rowwise_colmax, x, q, scale, colmax, R, C, sxr, sqr, eps, seed, offset, (unsigned *)workspace, st);
+}
+
+extern "C" int gnk_quantize_int8_colwise_given_absmax(const void *x, int x_dtype, int64_t P, int64_t Q, int64_t ld, int8_t *q, int64_t ldq,
+                                                      void *scale, const float *absmax, float eps, int sr, uint64_t seed, uint64_t offset,
+                                                      void *stream) {
+    if (!gnk_is_float_dtype(x_dtype)) return gnk_fail(GNK_ERR_BAD_ARG, "quantize_int8_colwise_given_absmax: input dtype code %d is not bf16/f16/f32", x_dtype);
+    if (P < 0 || Q < 0) return gnk_fail(GNK_ERR_BAD_ARG, "quantize_int8_colwise_given_absmax: negative size");
+    if (P == 0 || Q == 0) return gnk_fail(GNK_ERR_UNSUPPORTED, "quantize_int8_colwise_given_absmax: empty input");
+    if (!x || !q || !scale || !absmax) return gnk_fail(GNK_ERR_BAD_ARG, "quantize_int8_colwise_given_absmax: null pointer");
+    const int esz = gnk_dtype_size(x_dtype), vec = 16 / esz;
+    if (!(Q % vec == 0 && aligned(x, 16) && (ld * esz) % 16 == 0 && aligned(q, vec) && ldq % vec == 0 && ld >= Q && ldq >= Q))
+        return gnk_fail(GNK_ERR_UNSUPPORTED, "quantize_int8_colwise_given_absmax: rows must be contiguous, 16-byte aligned, Q a multiple of %d", vec);
+    int rc = gnk_init();
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    GNK_DISPATCH2(launch_colwise_given, x, q, scale, P, Q, ld, ldq, eps, seed, offset, (const unsigned *)absmax, st);
+#undef GNK_DISPATCH2
 }

@@ -14,6 +14,12 @@ from . import _cabi
 from ._lib import lib, lib_ops
 
 lib.define("quantize_int8(Tensor x, int dim, bool stochastic_rounding, float eps) -> (Tensor, Tensor)")
+# Fused dual-direction pair: every X, W and dY of a mixed-precision Linear is quantized along BOTH dims
+# per step (reference mixed_precision.py:100-108 with :154,:178,:186).  `quantize_int8_rowwise_colmax` is quantize_int8(x,
+# dim=1) that also returns the fp32 absmax of every column from the same read; `quantize_int8_colwise_given` is
+# quantize_int8(x, dim=0) for a caller who already holds that absmax (one read instead of two).
+lib.define("quantize_int8_rowwise_colmax(Tensor x, bool stochastic_rounding, float eps) -> (Tensor, Tensor, Tensor)")
+lib.define("quantize_int8_colwise_given(Tensor x, Tensor absmax, bool stochastic_rounding, float eps) -> (Tensor, Tensor)")
 
 _sr_calls = 0   # advances the Philox offset between stochastic-rounding calls
 
@@ -84,3 +90,97 @@ def _quantize_int8_hip(x: Tensor, dim: int, stochastic_rounding: bool, eps: floa
 def _dense(x: Tensor) -> bool:
     """Non-overlapping and dense in some dim order (a contiguous tensor or a transpose of one)."""
     return x.is_contiguous() or x.T.is_contiguous()
+
+
+# ------------------------------------------------------------------------------ fused dual-direction quantization
+def _sr_args(stochastic_rounding: bool):
+    global _sr_calls
+    if not stochastic_rounding:
+        return 0, 0
+    seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+    offset = (_sr_calls << 40) & 0xFFFFFFFFFFFFFFFF
+    _sr_calls += 1
+    return seed, offset
+
+
+def supports_rowwise_colmax(x: Tensor) -> bool:
+    """2-D device tensor with contiguous, 16-byte aligned rows of at most 6144 (16-bit) / 3072 (fp32) elements."""
+    if not (x.is_cuda and x.ndim == 2 and x.dtype in _cabi.DTYPE_CODE and x.dtype.is_floating_point and x.numel() > 0):
+        return False
+    if x.dtype not in (torch.bfloat16, torch.float16, torch.float32) or x.stride(1) != 1 or x.stride(0) < x.shape[1]:
+        return False
+    esz = x.element_size()
+    if x.data_ptr() % 16 or (x.stride(0) * esz) % 16:
+        return False
+    return _cabi.load().gnk_quantize_int8_rowwise_colmax_workspace_bytes(_cabi.DTYPE_CODE[x.dtype], x.shape[0], x.shape[1]) > 0
+
+
+def supports_colwise_given(x: Tensor) -> bool:
+    if not (x.is_cuda and x.ndim == 2 and x.dtype in (torch.bfloat16, torch.float16, torch.float32) and x.numel() > 0):
+        return False
+    esz = x.element_size()
+    return x.stride(1) == 1 and x.stride(0) >= x.shape[1] and x.shape[1] % (16 // esz) == 0 and x.data_ptr() % 16 == 0 and (x.stride(0) * esz) % 16 == 0
+
+
+def quantize_int8_rowwise_colmax(x: Tensor, stochastic_rounding: bool = False, *, eps: float = 1e-12):
+    """(int8 data, scale (R, 1) in x.dtype, column absmax (C,) fp32): quantize_int8(x, dim=1) plus amax|x| over dim 0."""
+    return lib_ops.quantize_int8_rowwise_colmax(x, stochastic_rounding, eps)
+
+
+def quantize_int8_colwise_given(x: Tensor, absmax: Tensor, stochastic_rounding: bool = False, *, eps: float = 1e-12):
+    """quantize_int8(x, dim=0) given amax|x| over dim 0 (fp32, (C,)): (int8 data, scale (1, C) in x.dtype)."""
+    return lib_ops.quantize_int8_colwise_given(x, absmax, stochastic_rounding, eps)
+
+
+@torch.library.impl(lib, "quantize_int8_rowwise_colmax", "Meta")
+def _rowwise_colmax_meta(x: Tensor, stochastic_rounding: bool, eps: float):
+    return torch.empty_like(x, dtype=torch.int8), x.new_empty((x.shape[0], 1)), x.new_empty((x.shape[1],), dtype=torch.float32)
+
+
+@torch.library.impl(lib, "quantize_int8_colwise_given", "Meta")
+def _colwise_given_meta(x: Tensor, absmax: Tensor, stochastic_rounding: bool, eps: float):
+    return torch.empty_like(x, dtype=torch.int8), x.new_empty((1, x.shape[1]))
+
+
+@torch.library.impl(lib, "quantize_int8_rowwise_colmax", "CUDA")
+def _rowwise_colmax_hip(x: Tensor, stochastic_rounding: bool, eps: float):
+    if not supports_rowwise_colmax(x):
+        raise RuntimeError(f"gn_kernels::quantize_int8_rowwise_colmax: unsupported input (shape {tuple(x.shape)}, strides {x.stride()}, dtype {x.dtype})")
+    R, C = x.shape
+    L = _cabi.load()
+    code = _cabi.DTYPE_CODE[x.dtype]
+    q = torch.empty_like(x, dtype=torch.int8)
+    if q.stride(1) != 1:
+        q = torch.empty((R, C), dtype=torch.int8, device=x.device)
+    scale = torch.empty((R, 1), dtype=x.dtype, device=x.device)
+    colmax = torch.empty((C,), dtype=torch.float32, device=x.device)
+    ws_bytes = L.gnk_quantize_int8_rowwise_colmax_workspace_bytes(code, R, C)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    seed, offset = _sr_args(stochastic_rounding)
+    with _cabi.device_of(x):
+        rc = L.gnk_quantize_int8_rowwise_colmax(x.data_ptr(), code, R, C, x.stride(0), q.data_ptr(), q.stride(0), scale.data_ptr(),
+                                                colmax.data_ptr(), eps, int(stochastic_rounding), seed, offset, ws.data_ptr(), ws_bytes,
+                                                _cabi.stream_of(x))
+    _cabi.check(rc, "quantize_int8_rowwise_colmax")
+    return q, scale, colmax
+
+
+@torch.library.impl(lib, "quantize_int8_colwise_given", "CUDA")
+def _colwise_given_hip(x: Tensor, absmax: Tensor, stochastic_rounding: bool, eps: float):
+    if not supports_colwise_given(x):
+        raise RuntimeError(f"gn_kernels::quantize_int8_colwise_given: unsupported input (shape {tuple(x.shape)}, strides {x.stride()}, dtype {x.dtype})")
+    P, Q = x.shape
+    if not (absmax.is_cuda and absmax.dtype is torch.float32 and absmax.numel() == Q and absmax.is_contiguous()):
+        raise RuntimeError("gn_kernels::quantize_int8_colwise_given: absmax must be a contiguous fp32 device tensor with one value per column")
+    L = _cabi.load()
+    q = torch.empty_like(x, dtype=torch.int8)
+    if q.stride(1) != 1:
+        q = torch.empty((P, Q), dtype=torch.int8, device=x.device)
+    scale = torch.empty((1, Q), dtype=x.dtype, device=x.device)
+    seed, offset = _sr_args(stochastic_rounding)
+    with _cabi.device_of(x):
+        rc = L.gnk_quantize_int8_colwise_given_absmax(x.data_ptr(), _cabi.DTYPE_CODE[x.dtype], P, Q, x.stride(0), q.data_ptr(), q.stride(0),
+                                                      scale.data_ptr(), absmax.data_ptr(), eps, int(stochastic_rounding), seed, offset,
+                                                      _cabi.stream_of(x))
+    _cabi.check(rc, "quantize_int8_colwise_given")
+    return q, scale

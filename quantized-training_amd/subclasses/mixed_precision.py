@@ -22,6 +22,7 @@ import torch.nn.functional as F
 import torch.utils._pytree as pytree
 from torch import Tensor, nn
 
+from gn_kernels import quantize as _qop
 from gn_kernels import scaled_mm
 
 from .int8 import quantize_int8
@@ -103,6 +104,88 @@ class MixedPrecisionLinearWeight(Tensor):
         return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Quantization plan of one Linear (device tensors).  The reference quantizes X, W and dY along BOTH dims every step,
+# each time from scratch (:100-108 called from :154, :178, :186), and q_proj / k_proj / v_proj (gate / up) re-quantize
+# the very same activation; under torch.compile Inductor merges those duplicates.  Without a tracing compiler the same
+# is done here explicitly -- identical arithmetic on identical inputs, so results do not change:
+#   * a small identity-keyed cache (storage address, offset, shape, strides, dtype, version counter; the source tensor
+#     is held so the address cannot be recycled) returns the int8 copy of a tensor that was already quantized along
+#     that dim.  Off under stochastic rounding: every call must draw its own random numbers.  ACTIVATIONS ONLY: the
+#     optimizer updates a wrapped weight through __torch_dispatch__, below the layer that bumps version counters, so
+#     the inner bf16 weight's counter never moves and a weight must be re-quantized every time;
+#   * for large tensors the row-wise pass also collects the fp32 column absmax (gn_kernels::quantize_int8_rowwise_colmax),
+#     which backward hands to the column-wise pass (gn_kernels::quantize_int8_colwise_given): one read instead of two.
+_FUSED_MIN_NUMEL = 48 * 1024 * 1024   # measured (tools/fused_quant_probe.py): the fused pair wins from ~32768 x 2048 up
+_CACHE_SLOTS = 4
+_cache_enabled = True
+_fused_enabled = True
+_cache: dict = {}
+
+
+def set_quantize_plan(*, cache: bool | None = None, fused: bool | None = None) -> tuple[bool, bool]:
+    """A/B switches (both on by default): the duplicate-quantization cache and the fused dual-direction kernels."""
+    global _cache_enabled, _fused_enabled
+    old = (_cache_enabled, _fused_enabled)
+    if cache is not None:
+        _cache_enabled = cache
+        _cache.clear()
+    if fused is not None:
+        _fused_enabled = fused
+    return old
+
+
+def _key(kind: str, t: Tensor):
+    return (kind, t.data_ptr(), t.storage_offset(), tuple(t.shape), t.stride(), t.dtype, t._version, t.device.index)
+
+
+def _cache_get(kind: str, t: Tensor, sr: bool):
+    if sr or not _cache_enabled:
+        return None
+    hit = _cache.get(_key(kind, t))
+    return hit[1] if hit is not None else None
+
+
+def _cache_put(kind: str, t: Tensor, sr: bool, value):
+    if sr or not _cache_enabled:
+        return
+    while len(_cache) >= 2 * _CACHE_SLOTS:
+        _cache.pop(next(iter(_cache)))                   # dicts keep insertion order: drop the oldest
+    _cache[_key(kind, t)] = (t, value)                   # holding t pins its memory, so the key cannot alias a new tensor
+
+
+def _plan_ok(*ts: Tensor) -> bool:
+    return all(t.is_cuda and t.ndim == 2 and t.stride(1) == 1 and t.numel() > 0 for t in ts)
+
+
+def _q_rows(x: Tensor, sr: bool, want_colmax: bool, cache: bool = True):
+    """quantize_int8(x, dim=1) -> (int8, scale (R, 1), fp32 column absmax or None)."""
+    stochastic, sr = sr, sr or not cache          # for the cache, "stochastic" and "do not cache" are the same thing
+    hit = _cache_get("row", x, sr)
+    if hit is not None and (hit[2] is not None or not want_colmax):
+        return hit
+    if want_colmax and _fused_enabled and x.numel() >= _FUSED_MIN_NUMEL and _qop.supports_rowwise_colmax(x):
+        out = _qop.quantize_int8_rowwise_colmax(x, stochastic)
+    else:
+        out = (*quantize_int8(x, stochastic, dim=1), None)
+    _cache_put("row", x, sr, out)
+    return out
+
+
+def _q_cols(x: Tensor, sr: bool, colmax: Tensor | None, cache: bool = True):
+    """quantize_int8(x, dim=0) -> (int8 in x's layout, scale (1, C)); `colmax` (if known) saves the absmax pass."""
+    stochastic, sr = sr, sr or not cache
+    hit = _cache_get("col", x, sr)
+    if hit is not None:
+        return hit
+    if colmax is not None and _qop.supports_colwise_given(x):
+        out = _qop.quantize_int8_colwise_given(x, colmax, stochastic)
+    else:
+        out = quantize_int8(x, stochastic, dim=0)
+    _cache_put("col", x, sr, out)
+    return out
+
+
 def _dynamic_int8_mm(A: Tensor, B: Tensor, sr: bool) -> Tensor:
     """(M, K) @ (K, N) with A quantized per row and B per column, both along K (reference :100-108).
     No `.contiguous()`: each int8 operand keeps its source layout and `scaled_mm` takes any strides."""
@@ -120,45 +203,67 @@ def _dynamic_mm(A: Tensor, B: Tensor, sr: bool, dtype: str) -> Tensor:
 
 
 class _Int8MixedPrecisionLinear(torch.autograd.Function):
-    @staticmethod
-    def forward(input: Tensor, weight: MixedPrecisionLinearWeight, bias: Tensor | None = None):
-        cfg = weight.config
-        if cfg.output:
-            lead = input.shape[:-1]
-            x2d = input.reshape(-1, weight.shape[1])
-            out = _dynamic_mm(x2d, weight._data.T, cfg.stochastic_rounding, cfg.dtype)      # A @ B.T
-            out = out.view(*lead, weight.shape[0])
-        else:
-            out = input @ weight.T
-        return out + bias if bias is not None else out
+    """reference :146-193.  Combined forward(ctx, ...) form (the reference uses forward + setup_context): the column
+    absmax collected by forward's row-wise passes travels to backward on ctx."""
 
     @staticmethod
-    def setup_context(ctx, inputs, output):
-        input, weight, bias = inputs
-        ctx.config = weight.config
-        ctx.save_for_backward(input, weight._data)    # bf16 tensors; int8 copies are re-derived in backward
+    def forward(ctx, input: Tensor, weight: MixedPrecisionLinearWeight, bias: Tensor | None = None):
+        cfg = weight.config
+        w = weight._data
+        x_cm = w_cm = None
+        if cfg.output:
+            lead = input.shape[:-1]
+            x2d = input.reshape(-1, w.shape[1])
+            if cfg.dtype == "int8" and _plan_ok(x2d, w):
+                sr = cfg.stochastic_rounding
+                xq, xs, x_cm = _q_rows(x2d, sr, cfg.grad_weight and ctx.needs_input_grad[1])
+                wq, ws, w_cm = _q_rows(w, sr, cfg.grad_input and ctx.needs_input_grad[0], cache=False)
+                out = scaled_mm(xq, wq.T, xs, ws.T)                                                # A @ B.T
+            else:
+                out = _dynamic_mm(x2d, w.T, cfg.stochastic_rounding, cfg.dtype)
+            out = out.view(*lead, w.shape[0])
+        else:
+            out = input @ w.T
+        ctx.config = cfg
+        ctx.save_for_backward(input, w)       # bf16 tensors; int8 copies are re-derived in backward (reference :160-165)
+        ctx.colmax = (x_cm, w_cm)
         ctx.bias = bias is not None
+        return out + bias if bias is not None else out
 
     @staticmethod
     def backward(ctx, grad_output):
         input, weight = ctx.saved_tensors
         cfg = ctx.config
+        x_cm, w_cm = ctx.colmax
+        sr = cfg.stochastic_rounding
         grad_input = grad_weight = grad_bias = None
 
         lead = grad_output.shape[:-1]
         go2d = grad_output.reshape(-1, weight.shape[0])
         x2d = input.reshape(-1, weight.shape[1])
+        want_gi = ctx.needs_input_grad[0]
+        want_gw = ctx.needs_input_grad[1]
+        plan = cfg.dtype == "int8" and _plan_ok(go2d, x2d, weight)
+        g_cm = None
 
-        if ctx.needs_input_grad[0]:
-            if cfg.grad_input:
-                grad_input = _dynamic_mm(go2d, weight, cfg.stochastic_rounding, cfg.dtype)           # A @ B
+        if want_gi:
+            if cfg.grad_input and plan:
+                gq, gs, g_cm = _q_rows(go2d, sr, want_gw and cfg.grad_weight)
+                wq, ws = _q_cols(weight, sr, w_cm, cache=False)
+                grad_input = scaled_mm(gq, wq, gs, ws)                                             # A @ B
+            elif cfg.grad_input:
+                grad_input = _dynamic_mm(go2d, weight, sr, cfg.dtype)
             else:
                 grad_input = go2d @ weight
             grad_input = grad_input.view(*lead, weight.shape[1])
 
-        if ctx.needs_input_grad[1]:
-            if cfg.grad_weight:
-                grad_weight = _dynamic_mm(x2d.T, go2d, cfg.stochastic_rounding, cfg.dtype).T          # (A.T @ B).T
+        if want_gw:
+            if cfg.grad_weight and plan:
+                xq, xs = _q_cols(x2d, sr, x_cm)                  # == quantize_int8(x2d.T, dim=1), transposed
+                gq0, gs0 = _q_cols(go2d, sr, g_cm)
+                grad_weight = scaled_mm(xq.T, gq0, xs.T, gs0).T                                    # (A.T @ B).T
+            elif cfg.grad_weight:
+                grad_weight = _dynamic_mm(x2d.T, go2d, sr, cfg.dtype).T
             else:
                 grad_weight = go2d.T @ x2d
 

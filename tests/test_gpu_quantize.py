@@ -140,3 +140,79 @@ def test_full_size_properties_4096(dim):
     assert (q != dev_formula).float().mean().item() < 1e-4
     q2, _ = quantize_int8((q.float() * s32), dim=dim)    # quantizing the dequantized tensor is a fixed point
     assert torch.equal(q2, q)
+
+
+# ------------------------------------------------------------------------------- fused dual-direction pair (8f rank 1)
+@pytest.mark.parametrize("shape", [(8, 8), (64, 256), (37, 512), (1000, 1024), (4099, 2048), (515, 4096), (300, 5632), (129, 6144), (64, 3072)])
+@pytest.mark.parametrize("name", ["bf16", "f16", "f32"])
+def test_rowwise_colmax_and_colwise_given_equal_the_separate_passes(shape, name):
+    """quantize_int8_rowwise_colmax == quantize_int8(dim=1) plus the exact fp32 column absmax; feeding that absmax to
+    quantize_int8_colwise_given == quantize_int8(dim=0): bit for bit, and both equal the CPU oracle."""
+    dt = FLOAT_DTYPES[name]
+    if name == "f32" and shape[1] > 3072:
+        pytest.skip("fused kernel holds rows of at most 3072 fp32 elements")
+    torch.manual_seed(shape[0] * 31 + shape[1])
+    x = (torch.randn(shape) * torch.rand(shape[0], 1) * 4 * torch.rand(1, shape[1])).to(dt)
+    x[0] = 0
+    x[:, 1] = 0                                # an all-zero column: absmax 0, scale 0, data 0
+    x[3, 2] = -7.5                             # column whose maximum is a negative value
+    xg = x.to(DEV)
+    assert qmod.supports_rowwise_colmax(xg) and qmod.supports_colwise_given(xg)
+    q, s, cm = qmod.quantize_int8_rowwise_colmax(xg)
+    q1, s1 = quantize_int8(xg, dim=1)
+    assert torch.equal(q, q1) and bits_equal(s, s1)
+    assert cm.dtype is torch.float32 and torch.equal(cm.cpu(), x.float().abs().amax(0))
+    q0, s0 = qmod.quantize_int8_colwise_given(xg, cm)
+    q0r, s0r = quantize_int8(xg, dim=0)
+    assert torch.equal(q0, q0r) and bits_equal(s0, s0r) and q0.stride() == xg.stride()
+    qo, so = oracle.quantize_int8(x, dim=1)
+    assert torch.equal(q.cpu(), qo) and bits_equal(s, so)
+    qo0, so0 = oracle.quantize_int8(x, dim=0)
+    assert torch.equal(q0.cpu(), qo0) and bits_equal(s0, so0)
+
+
+def test_rowwise_colmax_padded_rows_and_fallback_shapes():
+    """Row-padded views (stride > C) take the fused kernels; rows longer than the kernel holds report unsupported."""
+    torch.manual_seed(5)
+    base = torch.randn(300, 1024 + 64, device=DEV).bfloat16()
+    xg = base[:, :1024]
+    assert qmod.supports_rowwise_colmax(xg)
+    q, s, cm = qmod.quantize_int8_rowwise_colmax(xg)
+    q1, s1 = quantize_int8(xg.contiguous(), dim=1)
+    assert torch.equal(q, q1) and bits_equal(s, s1) and torch.equal(cm, xg.float().abs().amax(0))
+    q0, s0 = qmod.quantize_int8_colwise_given(xg, cm)
+    q0r, s0r = quantize_int8(xg.contiguous(), dim=0)
+    assert torch.equal(q0, q0r) and bits_equal(s0, s0r)
+    assert not qmod.supports_rowwise_colmax(torch.zeros(4, 8192, device=DEV).bfloat16())
+    assert not qmod.supports_rowwise_colmax(torch.zeros(8, 16, device=DEV).bfloat16().T)
+    with pytest.raises(RuntimeError):
+        qmod.quantize_int8_rowwise_colmax(torch.zeros(4, 8192, device=DEV).bfloat16())
+
+
+def test_rowwise_colmax_stochastic_rounding_statistics():
+    """SR through the fused kernels: unbiased (mean of dequantized == x within the CLT bound), both directions."""
+    torch.manual_seed(11)
+    x = torch.randn(256, 512, device=DEV).bfloat16()
+    acc_r = torch.zeros_like(x, dtype=torch.float32)
+    acc_c = torch.zeros_like(x, dtype=torch.float32)
+    n = 64
+    for _ in range(n):
+        q, s, cm = qmod.quantize_int8_rowwise_colmax(x, True)
+        acc_r += q.float() * s.float()
+        qc, sc = qmod.quantize_int8_colwise_given(x, cm, True)
+        acc_c += qc.float() * sc.float()
+    for acc, sc_ in ((acc_r, s), (acc_c, sc)):
+        err = (acc / n - x.float()).abs() / sc_.float().clamp_min(1e-12)      # in units of one quantization step
+        assert err.max().item() < 0.5 and err.mean().item() < 0.08           # sd of the mean <= 0.5 / sqrt(64) = 0.0625
+
+
+def test_full_size_fused_pair_32768x2048():
+    """Llama-1B activation shape: fused pair == separate passes, and the column absmax is exact."""
+    torch.manual_seed(2025)
+    x = torch.randn(32768, 2048, device=DEV).bfloat16()
+    q, s, cm = qmod.quantize_int8_rowwise_colmax(x)
+    q1, s1 = quantize_int8(x, dim=1)
+    assert torch.equal(q, q1) and bits_equal(s, s1) and torch.equal(cm, x.float().abs().amax(0))
+    q0, s0 = qmod.quantize_int8_colwise_given(x, cm)
+    q0r, s0r = quantize_int8(x, dim=0)
+    assert torch.equal(q0, q0r) and bits_equal(s0, s0r)

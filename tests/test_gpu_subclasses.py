@@ -61,6 +61,74 @@ def test_llama_sized_linear_vs_cpu_oracle_path(oracle_cpu_ops):
                       cpu.weight.grad._data.contiguous() if hasattr(cpu.weight.grad, "_data") else cpu.weight.grad.contiguous())
 
 
+@pytest.mark.parametrize("sizes", [(2048, 1024, 1024), (26624, 2048, 1024)])
+def test_quantization_plan_is_bit_identical_to_the_plain_path(sizes, monkeypatch):
+    """The duplicate-quantization cache and the fused dual-direction kernels (subclasses/mixed_precision.py) change which
+    kernels run, never the numbers: three Linears sharing one input (q/k/v of a Llama block), forward + backward, with
+    the plan on == with it off, bit for bit.  The larger case crosses the fused-kernel size threshold."""
+    import subclasses.mixed_precision as mp
+    T, K, N = sizes
+    torch.manual_seed(T + K)
+    lins = [nn.Linear(K, N, bias=False).to(BF).to(DEV) for _ in range(3)]
+    x = torch.randn(T, K, device=DEV, dtype=BF)
+    gys = [torch.randn(T, N, device=DEV, dtype=BF) for _ in range(3)]
+
+    def run(cache, fused):
+        old = mp.set_quantize_plan(cache=cache, fused=fused)
+        try:
+            ms = [convert_mixed_precision(copy.deepcopy(l)) for l in lins]
+            xi = x.clone().requires_grad_()
+            ys = [m(xi) for m in ms]
+            torch.autograd.backward(ys, gys)
+            gws = [m.weight.grad._data if hasattr(m.weight.grad, "_data") else m.weight.grad for m in ms]
+            return [y.detach() for y in ys], xi.grad, [g.contiguous() for g in gws]
+        finally:
+            mp.set_quantize_plan(cache=old[0], fused=old[1])
+
+    calls = {"n": 0}
+    real = mp._qop.quantize_int8_rowwise_colmax
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    monkeypatch.setattr(mp._qop, "quantize_int8_rowwise_colmax", counting)
+    ys0, gx0, gw0 = run(False, False)
+    assert calls["n"] == 0
+    ys1, gx1, gw1 = run(True, True)
+    if T * K >= mp._FUSED_MIN_NUMEL:
+        assert calls["n"] > 0, "the large case is meant to take the fused kernels"
+    for a, b in zip(ys0 + [gx0] + gw0, ys1 + [gx1] + gw1):
+        assert bits_equal(a, b)
+
+
+def test_quantization_cache_sees_in_place_updates():
+    """The cache key carries the tensor's version counter: an optimizer-style in-place update of the weight (or of the
+    input) must not return a stale int8 copy."""
+    import subclasses.mixed_precision as mp
+    torch.manual_seed(3)
+    lin = convert_mixed_precision(nn.Linear(512, 256, bias=False).to(BF).to(DEV))
+    x = torch.randn(128, 512, device=DEV, dtype=BF)
+    y0 = lin(x).detach().clone()
+    with torch.no_grad():
+        lin.weight.mul_(2.0)
+    y1 = lin(x).detach()
+    old = mp.set_quantize_plan(cache=False)
+    try:
+        y1_ref = lin(x).detach()
+    finally:
+        mp.set_quantize_plan(cache=old[0])
+    assert bits_equal(y1, y1_ref) and not bits_equal(y1, y0)
+    x.mul_(-0.5)
+    y2 = lin(x).detach()
+    old = mp.set_quantize_plan(cache=False)
+    try:
+        y2_ref = lin(x).detach()
+    finally:
+        mp.set_quantize_plan(cache=old[0])
+    assert bits_equal(y2, y2_ref)
+
+
 def test_training_step_runs_and_learns():
     torch.manual_seed(0)
     model = nn.Sequential(nn.Linear(256, 512), nn.GELU(), nn.Linear(512, 256)).to(BF).to(DEV)

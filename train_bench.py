@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--weight_decay", type=float, default=1e-2)
     ap.add_argument("--activation_checkpointing", action="store_true")
     ap.add_argument("--device", default="cuda")
+    ap.add_argument("--no_quantize_cache", action="store_true", help="A/B: re-quantize a tensor every time it is used (subclasses.mixed_precision.set_quantize_plan)")
+    ap.add_argument("--no_fused_quantize", action="store_true", help="A/B: never use the fused row-wise + column-absmax kernels")
     ap.add_argument("--gnk_debug_flags", type=int, default=0, help="A/B timing switches of libgnk_hip.so (gnk_set_debug_flags)")
     args = ap.parse_args()
 
@@ -84,6 +86,10 @@ def main():
     model = build_model(args.model, args.seq_len, dev)
     if args.activation_checkpointing:
         model.gradient_checkpointing_enable()
+    if args.no_quantize_cache or args.no_fused_quantize:
+        from subclasses import mixed_precision as _mp
+
+        _mp.set_quantize_plan(cache=not args.no_quantize_cache, fused=not args.no_fused_quantize)
     if args.gnk_debug_flags:
         from gn_kernels import _cabi
 
