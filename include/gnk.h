@@ -159,6 +159,30 @@ int gnk_fp8_mm(const void *A, int a_dtype, const void *B, int b_dtype, void *C, 
                int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, void *stream);
 
 /*
+ * OCP microscaling (MX) quantization, SURVEY.md section 8f rank 4.
+ * Replaces: kernels/gn_kernels/utils.py:83-107 (quantize_mx; scale rules :30-41 "nv" and :45-49 "ocp"; FP4 rounding
+ * table :52-80), eager ATen in the reference, ONE HBM-bound pass here.
+ * x: (M, N) of x_dtype, row stride ldx elements, N % 32 == 0.  q_format: 7 = FP4 e2m1, two values per byte (even column
+ * in the low nibble; q rows are N / 2 bytes), GNK_E4M3 or GNK_E5M2 (q rows are N bytes); ldq = row stride of q in BYTES.
+ * scales: one E8M0 byte per row and 32 columns, row stride lds bytes.  method: 0 = "ocp" (floor), 1 = "nv" (ceil).
+ */
+int gnk_quantize_mx(const void *x, int x_dtype, int64_t M, int64_t N, int64_t ldx, void *q, int q_format,
+                    int64_t ldq, void *scales, int64_t lds, int method, void *stream);
+
+/*
+ * MXFP4 GEMM:  C[m,n] = cast_out( sum_kb (A[m,kb] . B[n,kb]) * 2^(sA[m,kb]-127) * 2^(sB[n,kb]-127)  + bias[n] )
+ * over blocks kb of 32 k.  A: (M, K / 2) bytes, row stride lda BYTES; B: the operand as B.T, (N, K / 2) bytes, row stride
+ * ldb bytes (the reference requires B.T contiguous); scale_A (M, K / 32), scale_B (N, K / 32) E8M0 bytes with row strides
+ * ldsa / ldsb; bias NULL or N values of bias_dtype, added in fp32 before the cast; C row-major contiguous out_dtype.
+ * Replaces: kernels/gn_kernels/cutlass_mm.py:80-86 (mxfp4_mm) -> kernels/csrc/cutlass_sm120a_fp4.cu:42-136.  The scales
+ * are taken in quantize_mx's plain layout, not in CUTLASS's Blackwell-specific shuffled order (pack_block_scales_nv).
+ * K % 256 == 0 with 16-byte aligned rows runs on v_mfma_scale_f32_16x16x128_f8f6f4; anything else on a generic kernel.
+ */
+int gnk_mxfp4_mm(const void *A, const void *B, void *C, int out_dtype, const void *scale_A, const void *scale_B,
+                 const void *bias, int bias_dtype, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                 int64_t ldsa, int64_t ldsb, void *stream);
+
+/*
  * Test / tuning hook (no reference counterpart): force a GEMM kernel variant for subsequent
  * calls on this thread.  variant < 0 restores the built-in heuristic.  Returns the previous
  * value.  Variants are listed in csrc/gnk_gemm_dispatch.h.

@@ -101,6 +101,13 @@ __device__ __forceinline__ unsigned gnk_load_raw_rt(const void *p, int dt, int64
     const unsigned short *h = (const unsigned short *)p + i * w;
     return (unsigned)h[0] | ((unsigned)h[w - 1] << 16);
 }
+// e2m1 (FP4) code -> value: {0, .5, 1, 1.5, 2, 3, 4, 6} with the sign in bit 3 (kernels/gn_kernels/utils.py:114-118 of the reference)
+__device__ __forceinline__ float gnk_fp4_to_f32(unsigned c) {
+    const unsigned m = c & 7u;
+    const float mag = m < 2u ? 0.5f * (float)m : __uint_as_float(((126u + (m >> 1)) << 23) | ((m & 1u) << 22));   // 2^(e-1) * (1 + mant / 2)
+    return (c & 8u) ? -mag : mag;
+}
+
 __device__ __forceinline__ float gnk_raw_to_f32_rt(unsigned raw, int dt) {
     const float f32 = __uint_as_float(raw), bf = __uint_as_float(raw << 16), hf = gnk_f16_to_f32((unsigned short)(raw & 0xffffu));
     return dt == GNK_F32 ? f32 : dt == GNK_F16 ? hf : bf;

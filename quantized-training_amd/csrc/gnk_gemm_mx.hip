@@ -1,0 +1,219 @@
+// gnk_gemm_mx.hip -- MXFP4 GEMM on CDNA4's block-scaled MFMA.
+//
+//   C(M x N, bf16) = cast( sum over 32-k blocks kb of  (A_kb . B_kb) * 2^(sA[m,kb]-127) * 2^(sB[n,kb]-127)  (+ bias[n]) )
+//
+// Replaces: kernels/gn_kernels/cutlass_mm.py:80-86 (mxfp4_mm) -> kernels/csrc/cutlass_sm120a_fp4.cu:42-136, a CUTLASS
+// block-scaled GEMM for sm120a.  A is (M, K/2) bytes and B.T is (N, K/2) bytes, two e2m1 values per byte (even k in the
+// low nibble, kernels/gn_kernels/utils.py:52-80); scales are E8M0, one per row and 32 consecutive k.
+//
+// MI355X mapping: v_mfma_scale_f32_16x16x128_f8f6f4 with FP4 operands consumes, per lane l = 16 g + r, row r's 32 values
+// k = 32 g .. 32 g + 31 (16 bytes) and ONE E8M0 scale byte for exactly those 32 values (tools/probe_mx.hip checks this
+// against a CPU MX product): an MX block is a lane.  A row of 128 bytes (256 k) is therefore the int8 kernels' 128-byte
+// K-step unchanged -- same LDS-DMA staging, same XOR-swizzled K-major image, same 16-byte fragment reads, 2 MFMAs per tile
+// and step -- at twice the arithmetic per byte.  Scales: each lane fetches the 8 scale bytes of its rows for the NEXT step
+// (one 8-byte load per row tile, one K-step ahead, as the tile-scaled kernel does) and shifts its own block's byte to
+// byte 0 (op_sel 0).
+#include "gnk_gemm_dispatch.h"
+
+#include <string.h>
+
+namespace {
+
+typedef GemmCfg<128, 128, 2, 2, true, true, OP_F8, 0, 0, EPI_PLAIN> MxCfg;   // fp32 accumulators, plain epilogue maps
+
+struct MxParams {
+    GemmParams g;                 // A, B (packed bytes), C, M, N, K = packed bytes per row (k / 2), lda / ldb in bytes
+    const unsigned char *sa;      // (M, k / 32) E8M0, row stride ldsa bytes
+    const unsigned char *sb;      // (N, k / 32)
+    int64_t ldsa, ldsb;
+    const void *bias;             // (N) or nullptr
+    int bias_dtype;
+};
+
+constexpr int FMT_FP4 = 4;        // cbsz / blgp code of e2m1
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) mxfp4_kernel(const MxParams mp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef MxCfg Cfg;
+    constexpr int MT = Cfg::MT, NTL = Cfg::NTL;
+    const GemmParams &p = mp.g;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+    int tm, tn;
+    gnk_gemm::tile_of_block(p.grid_m, p.grid_n, tm, tn);
+    const int64_t m0 = (int64_t)tm * Cfg::BM, n0 = (int64_t)tn * Cfg::BN;
+    char *const As0 = smem, *const Bs0 = smem + 2 * Cfg::A_BYTES;
+
+    gnk_gemm::Stager<true, Cfg::BM, Cfg::NW> sa;
+    gnk_gemm::Stager<true, Cfg::BN, Cfg::NW> sb;
+    sa.init(p.A, p.lda, m0, p.M, wave, lane);
+    sb.init(p.B, p.ldb, n0, p.N, wave, lane);
+
+    v4f acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    // scale rows of this lane: operand row = lane & 15 of every 16-row tile (both operands); its MX block inside an MFMA = lane >> 4
+    const int r = lane & 15, sh = 8 * (lane >> 4);
+    const unsigned char *arow[MT], *brow[NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int64_t m = m0 + wm * Cfg::WTM + 16 * i + r;
+        m = m < p.M ? m : p.M - 1;
+        arow[i] = mp.sa + m * mp.ldsa;
+    }
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+        int64_t n = n0 + wn * Cfg::WTN + 16 * j + r;
+        n = n < p.N ? n : p.N - 1;
+        brow[j] = mp.sb + n * mp.ldsb;
+    }
+    v2i raw_a[MT], raw_b[NTL];
+    const int nk = (int)(p.K / GNK_BK);   // 128 packed bytes = 256 k = 8 MX blocks per step
+    if (nk > 0) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) raw_a[i] = *(const v2i *)(arow[i]);
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) raw_b[j] = *(const v2i *)(brow[j]);
+        sa.issue(As0, wave);
+        sb.issue(Bs0, wave);
+    }
+    for (int t = 0; t < nk; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // this step's scale bytes (arrived with the wait above): block lane >> 4 of each 128-k half, moved to byte 0
+        int sca[MT][2], scb[NTL][2];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            sca[i][0] = (int)(((unsigned)raw_a[i][0] >> sh) & 0xffu);
+            sca[i][1] = (int)(((unsigned)raw_a[i][1] >> sh) & 0xffu);
+        }
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            scb[j][0] = (int)(((unsigned)raw_b[j][0] >> sh) & 0xffu);
+            scb[j][1] = (int)(((unsigned)raw_b[j][1] >> sh) & 0xffu);
+        }
+        if (t + 1 < nk) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) raw_a[i] = *(const v2i *)(arow[i] + 8 * (t + 1));
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) raw_b[j] = *(const v2i *)(brow[j] + 8 * (t + 1));
+        }
+        const int cur = t & 1;
+        if (t + 1 < nk) {
+            sa.issue(As0 + (cur ^ 1) * Cfg::A_BYTES, wave);
+            sb.issue(Bs0 + (cur ^ 1) * Cfg::B_BYTES, wave);
+        }
+        const char *As = As0 + cur * Cfg::A_BYTES, *Bs = Bs0 + cur * Cfg::B_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            v8i fa[MT], fb[NTL];
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                const v4i f = gnk_gemm::load_frag<true, Cfg::BN>(Bs, wn * Cfg::WTN + 16 * j, ks, lane);
+                fb[j] = (v8i){f[0], f[1], f[2], f[3], 0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const v4i f = gnk_gemm::load_frag<true, Cfg::BM>(As, wm * Cfg::WTM + 16 * i, ks, lane);
+                fa[i] = (v8i){f[0], f[1], f[2], f[3], 0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j)   // matrix B feeds the MFMA's A port (a lane then owns 4 consecutive n of one m)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[j], fa[i], acc[i][j], FMT_FP4, FMT_FP4, 0, scb[j][ks], 0, sca[i][ks]);
+        }
+    }
+
+    // bias: fp32 add before the cast (cutlass_sm120a_fp4.cu:56-57: Add in the accumulator type, then Cast)
+    if (mp.bias) {
+        const int64_t ncol = n0 + wn * Cfg::WTN + 4 * (lane >> 4);
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int64_t n = ncol + 16 * j + q;
+                n = n < p.N ? n : p.N - 1;
+                const float b = gnk_load_scalar_rt(mp.bias, mp.bias_dtype, n);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i][j][q] = __fadd_rn(acc[i][j][q], b);
+            }
+    }
+    __syncthreads();   // every wave is done reading the operand tiles: LDS is free for the result staging
+    v4f(*no_accf)[1] = nullptr;
+    gnk_gemm::run_epilogue<Cfg>(p, acc, no_accf, smem, wave, lane, m0 + wm * Cfg::WTM, n0 + wn * Cfg::WTN);
+}
+
+// any sizes / alignment (k % 32 == 0 by format): one output per thread, blocks in ascending order
+__global__ void __launch_bounds__(256) mxfp4_generic_kernel(const MxParams mp) {
+    const GemmParams &p = mp.g;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.M * p.N) return;
+    const int64_t m = idx / p.N, n = idx - m * p.N;
+    const unsigned char *a = (const unsigned char *)p.A + m * p.lda, *b = (const unsigned char *)p.B + n * p.ldb;
+    const int64_t nblk = p.K / 16;   // 16 packed bytes per MX block
+    float acc = 0.f;
+    for (int64_t kb = 0; kb < nblk; ++kb) {
+        float part = 0.f;
+        for (int e = 0; e < 16; ++e) {
+            const unsigned ca = a[kb * 16 + e], cb = b[kb * 16 + e];
+            part += gnk_fp4_to_f32(ca & 15) * gnk_fp4_to_f32(cb & 15);
+            part += gnk_fp4_to_f32(ca >> 4) * gnk_fp4_to_f32(cb >> 4);
+        }
+        const float s = __uint_as_float((unsigned)mp.sa[m * mp.ldsa + kb] << 23) * __uint_as_float((unsigned)mp.sb[n * mp.ldsb + kb] << 23);
+        acc += part * s;
+    }
+    if (mp.bias) acc += gnk_load_scalar_rt(mp.bias, mp.bias_dtype, n);
+    if (p.out_dtype == GNK_BF16) ((unsigned short *)p.C)[idx] = gnk_f32_to_bf16(acc);
+    else if (p.out_dtype == GNK_F16) ((unsigned short *)p.C)[idx] = gnk_f32_to_f16(acc);
+    else ((float *)p.C)[idx] = acc;
+}
+
+inline bool al(const void *p, int a) { return ((uintptr_t)p % a) == 0; }
+
+}  // namespace
+
+extern "C" int gnk_mxfp4_mm(const void *A, const void *B, void *C, int out_dtype, const void *scale_A, const void *scale_B,
+                            const void *bias, int bias_dtype, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                            int64_t ldsa, int64_t ldsb, void *stream) {
+    if (M < 0 || N < 0 || K < 0) return gnk_fail(GNK_ERR_BAD_ARG, "mxfp4_mm: negative dimension");
+    if (K % 32 != 0) return gnk_fail(GNK_ERR_BAD_ARG, "mxfp4_mm: K = %lld is not a multiple of the MX block (32)", (long long)K);
+    if (!gnk_is_float_dtype(out_dtype)) return gnk_fail(GNK_ERR_BAD_ARG, "mxfp4_mm: output dtype code %d is not bf16/f16/f32", out_dtype);
+    if (bias && !gnk_is_float_dtype(bias_dtype)) return gnk_fail(GNK_ERR_BAD_ARG, "mxfp4_mm: bias dtype code %d is not bf16/f16/f32", bias_dtype);
+    if (M == 0 || N == 0) return GNK_OK;
+    if (!C || (K > 0 && (!A || !B || !scale_A || !scale_B))) return gnk_fail(GNK_ERR_BAD_ARG, "mxfp4_mm: null pointer");
+    if (lda < K / 2 || ldb < K / 2 || ldsa < K / 32 || ldsb < K / 32) return gnk_fail(GNK_ERR_BAD_ARG, "mxfp4_mm: a leading dimension is shorter than its row");
+    int rc = gnk_init();
+    if (rc) return rc;
+    MxParams mp;
+    memset(&mp, 0, sizeof(mp));
+    mp.g.A = (const char *)A; mp.g.B = (const char *)B; mp.g.C = C; mp.g.M = M; mp.g.N = N; mp.g.K = K / 2; mp.g.lda = lda; mp.g.ldb = ldb;
+    mp.g.out_dtype = out_dtype;
+    mp.sa = (const unsigned char *)scale_A; mp.sb = (const unsigned char *)scale_B; mp.ldsa = ldsa; mp.ldsb = ldsb;
+    mp.bias = bias; mp.bias_dtype = bias_dtype;
+    hipStream_t st = (hipStream_t)stream;
+    const bool fast = K >= 256 && K % 256 == 0 && al(A, 16) && al(B, 16) && lda % 16 == 0 && ldb % 16 == 0 && al(scale_A, 8) && al(scale_B, 8) &&
+                      ldsa % 8 == 0 && ldsb % 8 == 0 && M < (1LL << 31) && N < (1LL << 31) && lda * 256 < (1LL << 31) && ldb * 256 < (1LL << 31) &&
+                      ((M + 127) / 128) * ((N + 127) / 128) < (1LL << 31);
+    if (fast) {
+        mp.g.grid_m = (int)((M + 127) / 128);
+        mp.g.grid_n = (int)((N + 127) / 128);
+        static bool attr_set[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return gnk_fail(GNK_ERR_LAUNCH, "mxfp4_mm: no current HIP device");
+        if (!attr_set[dev]) {
+            if (hipFuncSetAttribute((const void *)mxfp4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MxCfg::LDS_BYTES) != hipSuccess)
+                return gnk_fail(GNK_ERR_LAUNCH, "mxfp4_mm: cannot reserve %d bytes of LDS", MxCfg::LDS_BYTES);
+            attr_set[dev] = true;
+        }
+        hipLaunchKernelGGL(mxfp4_kernel, dim3((unsigned)(mp.g.grid_m * mp.g.grid_n)), dim3(256), MxCfg::LDS_BYTES, st, mp);
+        return gnk_check_launch("mxfp4_mm");
+    }
+    if (M * N >= (1LL << 31) * 256) return gnk_fail(GNK_ERR_UNSUPPORTED, "mxfp4_mm: output too large for the generic kernel");
+    hipLaunchKernelGGL(mxfp4_generic_kernel, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, st, mp);
+    return gnk_check_launch("mxfp4_mm (generic)");
+}

@@ -1,10 +1,11 @@
 """gn_kernels for MI355X (gfx950): the reference's operator package, re-implemented on hand-written
 HIP kernels behind a C ABI (include/gnk.h).  Public names follow kernels/gn_kernels/__init__.py of
-the reference; names outside the INT8/FP8 scaled-matmul hot path import fine and raise
+the reference; names outside the INT8/FP8 scaled-matmul hot path and its MX extension import fine and raise
 NotImplementedError when called."""
 from . import _cabi
 from .fp8 import fp8_mm, scaled_fp8_mm
 from .mm import _triton_mm, int8_mm, scaled_mm
+from .mx import dequantize_mxfp4, mxfp4_mm, pack_block_scales_nv, quantize_mx
 from .quantize import quantize_int8
 
 
@@ -18,16 +19,12 @@ def _out_of_scope(name: str, why: str):
 
 int4_mm = _out_of_scope("int4_mm", "no INT4 MFMA on CDNA4")
 scaled_int4_mm = _out_of_scope("scaled_int4_mm", "no INT4 MFMA on CDNA4")
-mxfp4_mm = _out_of_scope("mxfp4_mm", "NVIDIA block-scale layout; MX formats are a later row")
 nvfp4_mm = _out_of_scope("nvfp4_mm", "NVIDIA-specific format")
 _triton_conv2d = _out_of_scope("_triton_conv2d", "conv2d is unmaintained upstream and not on the path")
 int8_conv2d = _out_of_scope("int8_conv2d", "conv2d is unmaintained upstream and not on the path")
 scaled_int8_conv2d = _out_of_scope("scaled_int8_conv2d", "conv2d is unmaintained upstream and not on the path")
-quantize_mx = _out_of_scope("quantize_mx", "feeds only the fp4 ops")
-quantize_nvfp4 = _out_of_scope("quantize_nvfp4", "feeds only the fp4 ops")
-quantize_nvfp4_triton = _out_of_scope("quantize_nvfp4_triton", "feeds only the fp4 ops")
-dequantize_mxfp4 = _out_of_scope("dequantize_mxfp4", "feeds only the fp4 ops")
-pack_block_scales_nv = _out_of_scope("pack_block_scales_nv", "feeds only the fp4 ops")
+quantize_nvfp4 = _out_of_scope("quantize_nvfp4", "NVIDIA-specific format")
+quantize_nvfp4_triton = _out_of_scope("quantize_nvfp4_triton", "NVIDIA-specific format")
 
 __all__ = [
     "int4_mm",

@@ -1,0 +1,125 @@
+"""GPU parity of the MX path (csrc/gnk_quantize_mx.hip, csrc/gnk_gemm_mx.hip) through the gn_kernels ops -> C ABI.
+quantize_mx: bit-exact against the goldens generated from the reference and against the numpy oracle.
+mxfp4_mm: the reference op is CUTLASS-on-Blackwell only (parity unpinned, oracle/mx_ref.py); the expectation is the
+exact product of the dequantized operands.  STATED TOLERANCE: |got - want| <= 1.6e-2 |want| + 2e-5 sum_k |a b| + 1e-5
+(bf16 output: the reference benchmark's assert_close default; the middle term allows for the MFMA's accumulation)."""
+import numpy as np
+import pytest
+import torch
+
+from gn_kernels import mx
+from oracle import mx_ref
+from tests._util import load
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+FMTS = {"fp4": mx.FP4, "e4m3": torch.float8_e4m3fn, "e5m2": torch.float8_e5m2}
+
+
+@pytest.mark.parametrize("method", ["ocp", "nv"])
+@pytest.mark.parametrize("fmt", list(FMTS))
+@pytest.mark.parametrize("xname", ["f32", "bf16"])
+def test_quantize_mx_golden_bit_exact(xname, fmt, method):
+    g = load("g7_quantize_mx.npz")
+    x = torch.from_numpy(g["x_f32"]) if xname == "f32" else torch.from_numpy(g["x_bf16"]).view(torch.bfloat16)
+    q, s = mx.quantize_mx(x.to(DEV), FMTS[fmt], method)
+    assert q.dtype is FMTS[fmt] and s.dtype is mx.E8M0
+    assert np.array_equal(s.view(torch.uint8).cpu().numpy(), g[f"s_{xname}_{fmt}_{method}"])
+    assert np.array_equal(q.view(torch.uint8).cpu().numpy(), g[f"q_{xname}_{fmt}_{method}"])
+
+
+@pytest.mark.parametrize("shape", [(1, 32), (37, 96), (256, 1024), (1000, 4096)])
+@pytest.mark.parametrize("fmt", list(FMTS))
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
+def test_quantize_mx_vs_oracle(shape, fmt, dt):
+    torch.manual_seed(shape[0] + shape[1])
+    x = (torch.randn(shape) * torch.logspace(-4, 4, shape[0]).unsqueeze(1)).to(dt)
+    x[0, :32] = 0
+    for method in ("ocp", "nv"):
+        q, s = mx.quantize_mx(x.to(DEV), FMTS[fmt], method)
+        qo, so = mx_ref.quantize_mx(x.float().numpy(), fmt, method)
+        assert np.array_equal(s.view(torch.uint8).cpu().numpy(), so)
+        assert np.array_equal(q.view(torch.uint8).cpu().numpy(), qo)
+
+
+def test_quantize_mx_takes_strided_input_and_rejects_bad_rows():
+    x = torch.randn(64, 320, device=DEV)
+    q, s = mx.quantize_mx(x[:, :256], mx.FP4)                 # row-padded view: no copy needed
+    q2, s2 = mx.quantize_mx(x[:, :256].contiguous(), mx.FP4)
+    assert torch.equal(q.view(torch.uint8), q2.view(torch.uint8)) and torch.equal(s.view(torch.uint8), s2.view(torch.uint8))
+    qt, st = mx.quantize_mx(x.T[:256], mx.FP4)                # column-major view: copied, then quantized
+    qo, so = mx_ref.quantize_mx(x.T[:256].contiguous().cpu().numpy(), "fp4")
+    assert np.array_equal(qt.view(torch.uint8).cpu().numpy(), qo) and np.array_equal(st.view(torch.uint8).cpu().numpy(), so)
+    with pytest.raises(RuntimeError):
+        torch.ops.gn_kernels.quantize_mx(torch.randn(4, 48, device=DEV), mx.FP4, "ocp")
+
+
+def _mx_case(M, N, K, seed, scale_span=6):
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randint(0, 256, (M, K // 2), dtype=torch.uint8, generator=g)
+    Bt = torch.randint(0, 256, (N, K // 2), dtype=torch.uint8, generator=g)
+    sA = torch.randint(127 - scale_span, 127 + scale_span, (M, K // 32), dtype=torch.uint8, generator=g)
+    sB = torch.randint(127 - scale_span, 127 + scale_span, (N, K // 32), dtype=torch.uint8, generator=g)
+    return A, Bt, sA, sB
+
+
+def _check_mm(A, Bt, sA, sB, bias=None, rows=None):
+    Ad, Bd = A.to(DEV).view(mx.FP4), Bt.to(DEV).view(mx.FP4).T
+    got = mx.mxfp4_mm(Ad, Bd, sA.to(DEV).view(mx.E8M0), sB.to(DEV).view(mx.E8M0), bias.to(DEV) if bias is not None else None)
+    assert got.dtype is torch.bfloat16 and got.shape == (A.shape[0], Bt.shape[0])
+    sel = slice(None) if rows is None else rows
+    An, sAn = A[sel].numpy(), sA[sel].numpy()
+    want = mx_ref.mxfp4_mm(An, Bt.numpy(), sAn, sB.numpy(), bias.float().numpy() if bias is not None else None)
+    mag = np.abs(mx_ref.dequantize_mxfp4(An, sAn)).astype(np.float64) @ np.abs(mx_ref.dequantize_mxfp4(Bt.numpy(), sB.numpy())).astype(np.float64).T
+    err = np.abs(got[sel].float().cpu().numpy().astype(np.float64) - want)
+    bound = 1.6e-2 * np.abs(want) + 2e-5 * mag + 1e-5
+    assert (err <= bound).all(), f"{int((err > bound).sum())} elements outside the tolerance; worst excess {(err - bound).max():.3e}"
+    return got
+
+
+@pytest.mark.parametrize("shape", [(128, 128, 256), (256, 384, 1024), (300, 200, 512), (1, 8, 256), (130, 70, 2048)])
+def test_mxfp4_mm_mfma_path_vs_oracle(shape):
+    M, N, K = shape
+    _check_mm(*_mx_case(M, N, K, seed=M * 3 + N + K))
+
+
+@pytest.mark.parametrize("shape", [(64, 48, 32), (33, 17, 96), (100, 52, 160)])
+def test_mxfp4_mm_generic_path_vs_oracle(shape):
+    M, N, K = shape
+    _check_mm(*_mx_case(M, N, K, seed=M + N + K))
+
+
+def test_mxfp4_mm_bias_and_packed_scales():
+    A, Bt, sA, sB = _mx_case(256, 128, 512, seed=9)
+    bias = torch.randn(128).bfloat16()
+    got = _check_mm(A, Bt, sA, sB, bias=bias)
+    packed = mx.mxfp4_mm(A.to(DEV).view(mx.FP4), Bt.to(DEV).view(mx.FP4).T, mx.pack_block_scales_nv(sA).to(DEV).view(mx.E8M0),
+                         mx.pack_block_scales_nv(sB).to(DEV).view(mx.E8M0), bias.to(DEV))
+    assert torch.equal(got, packed)
+
+
+def test_mxfp4_end_to_end_quantize_then_multiply():
+    """quantize_mx(FP4) of two random matrices, then mxfp4_mm: close to the fp32 product at FP4's accuracy, and equal (at
+    the stated tolerance) to the product of what the quantizer actually stored."""
+    torch.manual_seed(0)
+    X, W = torch.randn(512, 1024, device=DEV).bfloat16(), torch.randn(768, 1024, device=DEV).bfloat16()
+    xq, xs = mx.quantize_mx(X, mx.FP4)
+    wq, ws = mx.quantize_mx(W, mx.FP4)
+    out = mx.mxfp4_mm(xq, wq.T, xs, ws)
+    _check_mm(xq.view(torch.uint8).cpu(), wq.view(torch.uint8).cpu(), xs.view(torch.uint8).cpu(), ws.view(torch.uint8).cpu())
+    ref = X.float() @ W.float().T
+    rel = (out.float() - ref).norm() / ref.norm()
+    assert rel.item() < 0.2, rel.item()           # FP4 (1 mantissa bit) on Gaussian data: ~13 % relative error
+
+
+def test_full_size_4096_mxfp4():
+    A, Bt, sA, sB = _mx_case(4096, 4096, 4096, seed=2025, scale_span=3)
+    rows = torch.arange(0, 4096, 131)
+    _check_mm(A, Bt, sA, sB, rows=rows)
+
+
+def test_mx_errors_surface_as_exceptions():
+    A = torch.zeros(4, 24, dtype=torch.uint8, device=DEV).view(mx.FP4)          # K = 48: not a multiple of 32
+    s = torch.zeros(4, 1, dtype=torch.uint8, device=DEV).view(mx.E8M0)
+    with pytest.raises(RuntimeError):
+        mx.mxfp4_mm(A, A.T.contiguous().T[:, :4] if False else torch.zeros(4, 24, dtype=torch.uint8, device=DEV).view(mx.FP4).T, s, s)
