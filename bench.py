@@ -254,6 +254,31 @@ def main():
                         q[f"{R}x{C} {name}"]["hipgraph_us"] = f"capture failed: {type(exc).__name__}"
                 del x
             out["detail_quantize_bf16"] = q
+            # next rows: fused dual-direction quantize and the MX path, HIP-graph replay timing
+            nxt = {}
+            try:
+                from gn_kernels import mx
+                from gn_kernels import quantize as qmod
+
+                x = torch.randn(32768, 2048, device=dev).bfloat16()        # Llama-1B activation shape
+                _, _, cm = qmod.quantize_int8_rowwise_colmax(x)
+                t_sep = time_kernel_graph(lambda: (quantize_int8(x, dim=1), quantize_int8(x, dim=0)), per_graph=5)
+                t_fus = time_kernel_graph(lambda: (qmod.quantize_int8_rowwise_colmax(x), qmod.quantize_int8_colwise_given(x, cm)), per_graph=5)
+                nxt["quantize both dims 32768x2048 bf16"] = {"separate_us": round(t_sep * 1e3, 1), "fused_pair_us": round(t_fus * 1e3, 1),
+                                                            "fused_GB/s_at_6B_per_elem": round(6 * x.numel() / (t_fus * 1e-3) * 1e-9, 1)}
+                t_q = time_kernel_graph(lambda: mx.quantize_mx(x, mx.FP4), per_graph=5)
+                nxt["quantize_mx 32768x2048 bf16 -> fp4"] = {"us": round(t_q * 1e3, 1), "GB/s": round(x.numel() * (2 + 0.5 + 1 / 32) / (t_q * 1e-3) * 1e-9, 1)}
+                del x
+                A4 = torch.randint(0, 256, (S, S // 2), dtype=torch.uint8, device=dev).view(mx.FP4)
+                B4 = torch.randint(0, 256, (S, S // 2), dtype=torch.uint8, device=dev).view(mx.FP4).T
+                s4a = torch.randint(120, 134, (S, S // 32), dtype=torch.uint8, device=dev).view(mx.E8M0)
+                s4b = torch.randint(120, 134, (S, S // 32), dtype=torch.uint8, device=dev).view(mx.E8M0)
+                t_mm = time_kernel_graph(lambda: mx.mxfp4_mm(A4, B4, s4a, s4b), per_graph=10)
+                nxt[f"mxfp4_mm {S}^3"] = {"us": round(t_mm * 1e3, 1), "TFLOP/s": round(2 * S ** 3 / (t_mm * 1e-3) * 1e-12, 1),
+                                          "frac_of_fp4_dense_peak_10066": round(2 * S ** 3 / (t_mm * 1e-3) * 1e-12 / 10066.0, 4)}
+            except Exception as exc:   # detail only: never a reason to lose the bench line
+                nxt["error"] = f"{type(exc).__name__}: {exc}"
+            out["detail_next_rows"] = nxt
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

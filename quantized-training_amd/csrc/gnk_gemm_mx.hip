@@ -10,9 +10,9 @@
 // k = 32 g .. 32 g + 31 (16 bytes) and ONE E8M0 scale byte for exactly those 32 values (tools/probe_mx.hip checks this
 // against a CPU MX product): an MX block is a lane.  A row of 128 bytes (256 k) is therefore the int8 kernels' 128-byte
 // K-step unchanged -- same LDS-DMA staging, same XOR-swizzled K-major image, same 16-byte fragment reads, 2 MFMAs per tile
-// and step -- at twice the arithmetic per byte.  Scales: each lane fetches the 8 scale bytes of its rows for the NEXT step
-// (one 8-byte load per row tile, one K-step ahead, as the tile-scaled kernel does) and shifts its own block's byte to
-// byte 0 (op_sel 0).
+// and step -- at twice the arithmetic per byte.  Scales: the workgroup stages the scale bytes of its rows for 8 K-steps
+// at a time in LDS (coalesced 8-byte loads), every lane reads the 8 bytes of each of its row tiles per step from there
+// and shifts its own block's byte to byte 0 (op_sel 0).
 #include "gnk_gemm_dispatch.h"
 
 #include <string.h>
@@ -31,6 +31,7 @@ struct MxParams {
 };
 
 constexpr int FMT_FP4 = 4;        // cbsz / blgp code of e2m1
+constexpr int MX_LDS = MxCfg::LDS_BYTES + 2 * 128 * 64;   // operand buffers + the scale panel: 80 KiB, two workgroups per CU
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) mxfp4_kernel(const MxParams mp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -56,52 +57,70 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) m
 #pragma unroll
         for (int j = 0; j < NTL; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-    // scale rows of this lane: operand row = lane & 15 of every 16-row tile (both operands); its MX block inside an MFMA = lane >> 4
+    // ---- scales.  Each lane needs, per K-step, 8 scale bytes of every operand row it feeds (row = lane & 15 of each 16-row
+    // tile; its own MX block inside an MFMA = lane >> 4).  Fetching them per lane from global memory (16 rows x 8 B per
+    // load instruction) took as long as the MFMAs (90 vs 46 us at 4096^3), so the workgroup stages a PANEL -- the scale
+    // bytes of its 128 + 128 rows for 8 K-steps, 64 B per row, 16 KiB -- in LDS behind the operand buffers with coalesced
+    // 8-byte loads, once per 8 steps, and every lane reads its 8 bytes per row tile and step from there.
+    constexpr int PSTEPS = 8, PROW = 8 * PSTEPS;           // K-steps per panel, bytes per panel row
+    char *const panel = smem + Cfg::LDS_BYTES;             // [2 operands][128 rows][PROW]
     const int r = lane & 15, sh = 8 * (lane >> 4);
-    const unsigned char *arow[MT], *brow[NTL];
+    const int nk = (int)(p.K / GNK_BK);                    // 128 packed bytes = 256 k = 8 MX blocks per step
+    const int64_t row_bytes = p.K / 16;                    // scale bytes per row (k / 32)
+    // this thread's 8 panel chunks (8 B each): chunk c = tid + 256 u -> operand c >> 10, row (c >> 3) & 127, part c & 7
+    const unsigned char *csrc[8];
+    int cpart[8];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        int64_t m = m0 + wm * Cfg::WTM + 16 * i + r;
-        m = m < p.M ? m : p.M - 1;
-        arow[i] = mp.sa + m * mp.ldsa;
+    for (int u = 0; u < 8; ++u) {
+        const int c = (int)threadIdx.x + 256 * u, op = c >> 10, row = (c >> 3) & 127;
+        cpart[u] = c & 7;
+        int64_t g = (op ? n0 : m0) + row;
+        const int64_t last = (op ? p.N : p.M) - 1;
+        g = g < last ? g : last;
+        csrc[u] = (op ? mp.sb + g * mp.ldsb : mp.sa + g * mp.ldsa) + 8 * cpart[u];
     }
+    v2i pnl[8];
+    auto panel_fetch = [&](int pn) {                        // global -> registers (bytes past the row end are never used)
 #pragma unroll
-    for (int j = 0; j < NTL; ++j) {
-        int64_t n = n0 + wn * Cfg::WTN + 16 * j + r;
-        n = n < p.N ? n : p.N - 1;
-        brow[j] = mp.sb + n * mp.ldsb;
-    }
-    v2i raw_a[MT], raw_b[NTL];
-    const int nk = (int)(p.K / GNK_BK);   // 128 packed bytes = 256 k = 8 MX blocks per step
+        for (int u = 0; u < 8; ++u) {
+            pnl[u] = (v2i){0, 0};
+            if ((int64_t)PROW * pn + 8 * cpart[u] < row_bytes) pnl[u] = *(const v2i *)(csrc[u] + (int64_t)PROW * pn);
+        }
+    };
+    auto panel_store = [&]() {                              // registers -> LDS
+#pragma unroll
+        for (int u = 0; u < 8; ++u) *(GNK_LDS v2i *)(GNK_LDS char *)(panel + ((int)threadIdx.x + 256 * u) * 8) = pnl[u];
+    };
     if (nk > 0) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i) raw_a[i] = *(const v2i *)(arow[i]);
-#pragma unroll
-        for (int j = 0; j < NTL; ++j) raw_b[j] = *(const v2i *)(brow[j]);
+        panel_fetch(0);
         sa.issue(As0, wave);
         sb.issue(Bs0, wave);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // the 8 panel loads are older than the 8 LDS-DMA pieces
+        panel_store();
     }
     for (int t = 0; t < nk; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        // this step's scale bytes (arrived with the wait above): block lane >> 4 of each 128-k half, moved to byte 0
+        const int ts = t % PSTEPS;
+        if (ts == 0 && t > 0) {                             // the panel of steps t .. t + 7 was fetched during step t - 1
+            panel_store();
+            __syncthreads();
+        }
+        // this step's scale bytes: block lane >> 4 of each 128-k half, moved to byte 0 (op_sel 0)
         int sca[MT][2], scb[NTL][2];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            sca[i][0] = (int)(((unsigned)raw_a[i][0] >> sh) & 0xffu);
-            sca[i][1] = (int)(((unsigned)raw_a[i][1] >> sh) & 0xffu);
+            const v2i w = *(const GNK_LDS v2i *)(const GNK_LDS char *)(panel + (wm * Cfg::WTM + 16 * i + r) * PROW + 8 * ts);
+            sca[i][0] = (int)(((unsigned)w[0] >> sh) & 0xffu);
+            sca[i][1] = (int)(((unsigned)w[1] >> sh) & 0xffu);
         }
 #pragma unroll
         for (int j = 0; j < NTL; ++j) {
-            scb[j][0] = (int)(((unsigned)raw_b[j][0] >> sh) & 0xffu);
-            scb[j][1] = (int)(((unsigned)raw_b[j][1] >> sh) & 0xffu);
+            const v2i w = *(const GNK_LDS v2i *)(const GNK_LDS char *)(panel + (128 + wn * Cfg::WTN + 16 * j + r) * PROW + 8 * ts);
+            scb[j][0] = (int)(((unsigned)w[0] >> sh) & 0xffu);
+            scb[j][1] = (int)(((unsigned)w[1] >> sh) & 0xffu);
         }
-        if (t + 1 < nk) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i) raw_a[i] = *(const v2i *)(arow[i] + 8 * (t + 1));
-#pragma unroll
-            for (int j = 0; j < NTL; ++j) raw_b[j] = *(const v2i *)(brow[j] + 8 * (t + 1));
-        }
+        if (ts == PSTEPS - 1 && t + 1 < nk && !(p.debug & 128)) panel_fetch((t + 1) / PSTEPS);   // debug flag 128: timing only
         const int cur = t & 1;
         if (t + 1 < nk) {
             sa.issue(As0 + (cur ^ 1) * Cfg::A_BYTES, wave);
@@ -195,6 +214,7 @@ extern "C" int gnk_mxfp4_mm(const void *A, const void *B, void *C, int out_dtype
     mp.g.out_dtype = out_dtype;
     mp.sa = (const unsigned char *)scale_A; mp.sb = (const unsigned char *)scale_B; mp.ldsa = ldsa; mp.ldsb = ldsb;
     mp.bias = bias; mp.bias_dtype = bias_dtype;
+    mp.g.debug = gnk_debug_flags_get();
     hipStream_t st = (hipStream_t)stream;
     const bool fast = K >= 256 && K % 256 == 0 && al(A, 16) && al(B, 16) && lda % 16 == 0 && ldb % 16 == 0 && al(scale_A, 8) && al(scale_B, 8) &&
                       ldsa % 8 == 0 && ldsb % 8 == 0 && M < (1LL << 31) && N < (1LL << 31) && lda * 256 < (1LL << 31) && ldb * 256 < (1LL << 31) &&
@@ -206,11 +226,11 @@ extern "C" int gnk_mxfp4_mm(const void *A, const void *B, void *C, int out_dtype
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return gnk_fail(GNK_ERR_LAUNCH, "mxfp4_mm: no current HIP device");
         if (!attr_set[dev]) {
-            if (hipFuncSetAttribute((const void *)mxfp4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MxCfg::LDS_BYTES) != hipSuccess)
-                return gnk_fail(GNK_ERR_LAUNCH, "mxfp4_mm: cannot reserve %d bytes of LDS", MxCfg::LDS_BYTES);
+            if (hipFuncSetAttribute((const void *)mxfp4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS) != hipSuccess)
+                return gnk_fail(GNK_ERR_LAUNCH, "mxfp4_mm: cannot reserve %d bytes of LDS", MX_LDS);
             attr_set[dev] = true;
         }
-        hipLaunchKernelGGL(mxfp4_kernel, dim3((unsigned)(mp.g.grid_m * mp.g.grid_n)), dim3(256), MxCfg::LDS_BYTES, st, mp);
+        hipLaunchKernelGGL(mxfp4_kernel, dim3((unsigned)(mp.g.grid_m * mp.g.grid_n)), dim3(256), MX_LDS, st, mp);
         return gnk_check_launch("mxfp4_mm");
     }
     if (M * N >= (1LL << 31) * 256) return gnk_fail(GNK_ERR_UNSUPPORTED, "mxfp4_mm: output too large for the generic kernel");
