@@ -57,7 +57,8 @@ def test_public_names_match_the_reference_package():
     with pytest.raises(NotImplementedError):
         gn_kernels.int4_mm(torch.zeros(2, 2, dtype=torch.int8), torch.zeros(2, 2, dtype=torch.int8))
     with pytest.raises(NotImplementedError):
-        gn_kernels.mxfp4_mm(None, None, None, None)
+        gn_kernels.nvfp4_mm(None, None, None, None, None)
+    assert str(torch.ops.gn_kernels.mxfp4_mm.default._schema) == "gn_kernels::mxfp4_mm(Tensor A, Tensor B, Tensor scale_A, Tensor scale_B, Tensor? bias) -> Tensor"
 
 
 def test_op_schemas_match_the_reference():
