@@ -49,22 +49,46 @@ template <int EB, int MB> __device__ __forceinline__ unsigned fp8_code(float y) 
     return sign | code;
 }
 
+typedef short v2s __attribute__((ext_vector_type(2)));
+template <int SEL> __device__ __forceinline__ unsigned hw_fp4(unsigned old, float a, float b) { return __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(old, a, b, 1.0f, SEL); }
+template <int FMT, bool HI> __device__ __forceinline__ v2s hw_fp8(v2s old, float a, float b) {
+    if constexpr (FMT == GNK_E4M3) return __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(old, a, b, 1.0f, HI);
+    else return __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(old, a, b, 1.0f, HI);
+}
+
 template <int DT> struct MxElem;
 template <> struct MxElem<GNK_BF16> { static constexpr int VEC = 8; };
 template <> struct MxElem<GNK_F16>  { static constexpr int VEC = 8; };
 template <> struct MxElem<GNK_F32>  { static constexpr int VEC = 4; };
+
+constexpr int MX_UNR = 4;   // 16-byte chunks per thread, all loaded before the first is used (bytes in flight: one chunk per thread
+                            // kept 32 KiB per CU in flight, half of what the HBM latency needs)
 
 template <int DT, int FMT, int METHOD>
 __global__ void __launch_bounds__(256) quantize_mx_kernel(const char *__restrict__ x, unsigned char *__restrict__ q, unsigned char *__restrict__ scales,
                                                           int64_t M, int64_t N, int64_t ldx_bytes, int64_t ldq, int64_t lds) {
     constexpr int VEC = MxElem<DT>::VEC, LPB = 32 / VEC;       // lanes per MX block
     const int64_t chunks_per_row = N / VEC;
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t total = M * chunks_per_row;
-    const bool live = gid < total;                              // whole blocks are live or dead together (N % 32 == 0)
-    const int64_t row = live ? gid / chunks_per_row : 0, ch = live ? gid - row * chunks_per_row : 0;
-    v4i raw = {0, 0, 0, 0};
-    if (live) raw = *(const v4i *)(x + row * ldx_bytes + ch * 16);
+    v4i raws[MX_UNR];
+    int64_t rows[MX_UNR], chs[MX_UNR];
+    bool lives[MX_UNR];
+#pragma unroll
+    for (int u = 0; u < MX_UNR; ++u) {
+        const int64_t gid = ((int64_t)blockIdx.x * MX_UNR + u) * 256 + threadIdx.x;
+        lives[u] = gid < total;                                 // whole blocks are live or dead together (N % 32 == 0)
+        // 32-bit division (the host guarantees total < 2^32): a 64-bit one per chunk was most of this kernel's time
+        const unsigned r32 = lives[u] ? (unsigned)gid / (unsigned)chunks_per_row : 0u;
+        rows[u] = r32;
+        chs[u] = lives[u] ? (int64_t)((unsigned)gid - r32 * (unsigned)chunks_per_row) : 0;
+        raws[u] = (v4i){0, 0, 0, 0};
+        if (lives[u]) raws[u] = *(const v4i *)(x + rows[u] * ldx_bytes + chs[u] * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < MX_UNR; ++u) {
+    const v4i raw = raws[u];
+    const bool live = lives[u];
+    const int64_t row = rows[u], ch = chs[u];
     float f[VEC];
     if constexpr (DT == GNK_F32) {
 #pragma unroll
@@ -96,13 +120,34 @@ __global__ void __launch_bounds__(256) quantize_mx_kernel(const char *__restrict
         bits = up ? e + 1 : e;
     }
     const float div = fmaxf(__uint_as_float((unsigned)bits << 23), 1e-12f);
+    // bits in [88, 253]: the divisor is 2^(bits - 127) >= 2^-39 > 1e-12 and its reciprocal 2^(127 - bits) is a normal fp32 number, so
+    // x * reciprocal IS x / divisor (the exact quotient, rounded once either way) at 1 VALU instead of ~10.  Wave-uniform choice.
+    const bool pow2 = __all(!live || (bits >= 88 && bits <= 253));
+    const float rcp = __uint_as_float((unsigned)(254 - bits) << 23);
+    auto quot = [&](float v) { return pow2 ? __fmul_rn(v, rcp) : __fdiv_rn(v, div); };
+    // Rounding: the reference's FP4 table and its fp8 casts are round-to-nearest-even onto the target grid, which is what
+    // gfx950's v_cvt_scalef32_pk_{fp4,fp8,bf8}_f32 do (scale operand 1.0: the division and the clip stay explicit, the
+    // clip because amax / scale may exceed the format maximum under the "ocp" rule).  The integer restatements above remain
+    // the path for blocks whose divisor is not a power of two, and the tests hold both to the same goldens.
     if constexpr (FMT == MX_FP4) {
         unsigned word = 0u;
+        if (pow2) {
+            float y[VEC];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            float y = __fdiv_rn(f[i], div);
-            y = fminf(fmaxf(y, -DT_AMAX), DT_AMAX);
-            word |= fp4_code(y) << (4 * i);
+            for (int i = 0; i < VEC; ++i) y[i] = fminf(fmaxf(__fmul_rn(f[i], rcp), -DT_AMAX), DT_AMAX);
+            word = hw_fp4<0>(word, y[0], y[1]);
+            word = hw_fp4<1>(word, y[2], y[3]);
+            if constexpr (VEC == 8) {
+                word = hw_fp4<2>(word, y[4], y[5]);
+                word = hw_fp4<3>(word, y[6], y[7]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float y = quot(f[i]);
+                y = fminf(fmaxf(y, -DT_AMAX), DT_AMAX);
+                word |= fp4_code(y) << (4 * i);
+            }
         }
         if (live) {
             if constexpr (VEC == 8) *(unsigned *)(q + row * ldq + ch * 4) = word;
@@ -110,12 +155,25 @@ __global__ void __launch_bounds__(256) quantize_mx_kernel(const char *__restrict
         }
     } else {
         unsigned w[2] = {0u, 0u};
+        if (pow2) {
+            float y[VEC];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            float y = __fdiv_rn(f[i], div);
-            y = fminf(fmaxf(y, -DT_AMAX), DT_AMAX);
-            const unsigned c = FMT == GNK_E4M3 ? fp8_code<4, 3>(y) : fp8_code<5, 2>(y);
-            w[i >> 2] |= c << (8 * (i & 3));
+            for (int i = 0; i < VEC; ++i) y[i] = fminf(fmaxf(__fmul_rn(f[i], rcp), -DT_AMAX), DT_AMAX);
+#pragma unroll
+            for (int h = 0; h < VEC / 4; ++h) {
+                v2s pk = {0, 0};
+                pk = hw_fp8<FMT, false>(pk, y[4 * h], y[4 * h + 1]);
+                pk = hw_fp8<FMT, true>(pk, y[4 * h + 2], y[4 * h + 3]);
+                w[h] = __builtin_bit_cast(unsigned, pk);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float y = quot(f[i]);
+                y = fminf(fmaxf(y, -DT_AMAX), DT_AMAX);
+                const unsigned c = FMT == GNK_E4M3 ? fp8_code<4, 3>(y) : fp8_code<5, 2>(y);
+                w[i >> 2] |= c << (8 * (i & 3));
+            }
         }
         if (live) {
             if constexpr (VEC == 8) *(v2i *)(q + row * ldq + ch * 8) = (v2i){(int)w[0], (int)w[1]};
@@ -123,13 +181,14 @@ __global__ void __launch_bounds__(256) quantize_mx_kernel(const char *__restrict
         }
     }
     if (live && (ch % LPB) == 0) scales[row * lds + ch / LPB] = (unsigned char)bits;
+    }
 }
 
 template <int DT, int FMT>
 int launch_mx(int method, const void *x, void *q, void *scales, int64_t M, int64_t N, int64_t ldx, int64_t ldq, int64_t lds, hipStream_t st) {
     constexpr int VEC = MxElem<DT>::VEC;
     const int64_t total = M * (N / VEC);
-    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    const dim3 grid((unsigned)((total + 256 * MX_UNR - 1) / (256 * MX_UNR))), block(256);
     const int64_t ldx_bytes = ldx * (16 / VEC);
     if (method == 0)
         hipLaunchKernelGGL((quantize_mx_kernel<DT, FMT, 0>), grid, block, 0, st, (const char *)x, (unsigned char *)q, (unsigned char *)scales, M, N, ldx_bytes, ldq, lds);
@@ -161,7 +220,7 @@ extern "C" int gnk_quantize_mx(const void *x, int x_dtype, int64_t M, int64_t N,
     if (ldx < N || ldq < qrow || lds < N / 32) return gnk_fail(GNK_ERR_BAD_ARG, "quantize_mx: a leading dimension is shorter than its row");
     if (((uintptr_t)x & 15) || (ldx * esz) % 16 || ((uintptr_t)q & 7) || ldq % 8)
         return gnk_fail(GNK_ERR_UNSUPPORTED, "quantize_mx: rows of x must be 16-byte aligned, rows of q 8-byte aligned");
-    if (M * (N / 4) >= (1LL << 31) * 256) return gnk_fail(GNK_ERR_UNSUPPORTED, "quantize_mx: tensor too large for one launch");
+    if (M * (N / 4) >= (1LL << 32)) return gnk_fail(GNK_ERR_UNSUPPORTED, "quantize_mx: tensor too large for one launch (2^34 elements)");
     int rc = gnk_init();
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
