@@ -167,6 +167,140 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) m
     gnk_gemm::run_epilogue<Cfg>(p, acc, no_accf, smem, wave, lane, m0 + wm * Cfg::WTM, n0 + wn * Cfg::WTN);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 256 x 256 tile, 8 waves, four 64-byte stages, two-phase ping-pong: the int8 program of gnk_gemm_pp2.h with the scaled FP4
+// MFMA.  One 64-byte stage row is 128 k = exactly one v_mfma_scale_f32_16x16x128_f8f6f4 per 16 x 16 tile, and its four MX
+// blocks are the four 16-byte chunks the int8 fragment read already hands to lanes 16 g .. 16 g + 15.  The scale bytes ride
+// the same LDS-DMA pipeline: with the loads of every FOURTH stage each wave issues one more global_load_lds, 16 bytes per
+// lane (lane -> one of the tile's 512 operand rows, its scale bytes of four stages), into a two-slot panel; it lands under the
+// same counted vmcnt waits as that stage's data, and the LOAD phase reads one dword per row tile next to the fragments.
+// (One 4-byte load per wave and stage -- 64 cache lines per instruction, as many as the four data pieces together --
+// held the kernel at the 128 x 128 kernel's speed.)
+typedef GemmCfg<256, 256, 2, 4, true, true, OP_F8, 0, 0, EPI_PLAIN> Mx256Cfg;
+constexpr int MX256_SK = 64, MX256_NST = 4, MX256_OPER = 256 * MX256_SK, MX256_PNL = 512 * 16;
+constexpr int MX256_LDS = 2 * MX256_NST * MX256_OPER + 2 * MX256_PNL;   // 128 KiB + two 8 KiB scale panels
+
+__global__ void __launch_bounds__(512) mxfp4_256_kernel(const MxParams mp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const GemmParams &p = mp.g;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    int tm, tn;
+    gnk_gemm::tile_of_block(p.grid_m, p.grid_n, tm, tn);
+    const int64_t m0 = (int64_t)tm * 256, n0 = (int64_t)tn * 256;
+    char *const Abuf = smem, *const Bbuf = smem + MX256_NST * MX256_OPER, *const Sbuf = smem + 2 * MX256_NST * MX256_OPER;
+
+    gnk_gemm::Stager64<true> sa, sb;
+    sa.init(p.A, p.lda, m0, p.M, wave, lane);
+    sb.init(p.B, p.ldb, n0, p.N, wave, lane);
+    // scale source of this lane: operand row 64 * wave + lane of the tile's 256 A rows followed by its 256 B rows
+    const unsigned char *ssrc;
+    {
+        const int idx = 64 * wave + lane;
+        int64_t g = idx < 256 ? m0 + idx : n0 + (idx - 256);
+        const int64_t last = (idx < 256 ? p.M : p.N) - 1;
+        g = g < last ? g : last;
+        ssrc = idx < 256 ? mp.sa + g * mp.ldsa : mp.sb + g * mp.ldsb;
+    }
+    auto issue_stage = [&](int st) {                            // stage st -> buffer st & 3; every fourth stage brings its panel
+        if ((st & 3) == 0 && !(p.debug & 128)) {   // debug flag 128 (timing only, wrong results): no scale traffic
+            __builtin_amdgcn_global_load_lds((const GNK_GLOBAL void *)ssrc, (GNK_LDS void *)(Sbuf + ((st >> 2) & 1) * MX256_PNL + wave * 1024), 16, 0, 0);
+            ssrc += 16;
+        }
+        sa.issue(Abuf + (st & 3) * MX256_OPER, wave);
+        sb.issue(Bbuf + (st & 3) * MX256_OPER, wave);
+    };
+
+    v4f acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+    v4i fa[8], fb[4];
+    int sca[8], scb[4];
+    const int r = lane & 15, g = lane >> 4;
+    const bool no_scale_reads = p.debug & 1024;   // debug flag 1024 (timing only): unit scales instead of the LDS panel reads
+    auto load_frags = [&](int st) {
+        const char *As = Abuf + (st & 3) * MX256_OPER, *Bs = Bbuf + (st & 3) * MX256_OPER, *Ss = Sbuf + ((st >> 2) & 1) * MX256_PNL + 4 * (st & 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            fb[j] = *(const GNK_LDS v4i *)(const GNK_LDS char *)(Bs + gnk_k64_frag16_offset(wn * 64 + 16 * j, lane));
+            scb[j] = no_scale_reads ? 127 : (int)*(const GNK_LDS unsigned char *)(Ss + (256 + wn * 64 + 16 * j + r) * 16 + g);   // ds_read_u8: the lane's own block, already at byte 0
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            fa[i] = *(const GNK_LDS v4i *)(const GNK_LDS char *)(As + gnk_k64_frag16_offset(wm * 128 + 16 * i, lane));
+            sca[i] = no_scale_reads ? 127 : (int)*(const GNK_LDS unsigned char *)(Ss + (wm * 128 + 16 * i + r) * 16 + g);
+        }
+    };
+
+    const int ns = (int)(p.K / MX256_SK);
+    const int npro = ns < MX256_NST ? ns : MX256_NST;
+    for (int s = 0; s < npro; ++s) issue_stage(s);               // the panel of stages 0..3 is the oldest load
+    if (npro == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (npro == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (npro == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    gnk_gemm::pp2_phase_barrier();
+    load_frags(0);
+    if (npro == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // stage 1 must have landed before the first LOAD phase reads it
+    else if (npro == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    gnk_gemm::pp2_phase_barrier();
+    if (wm == 1) gnk_gemm::pp2_phase_barrier();   // stagger: group 1 runs one phase behind group 0
+
+    for (int s = 0; s < ns; ++s) {
+        // ---- MFMA phase (matrix B feeds the MFMA's A port: a lane then owns 4 consecutive n of one m)
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const v8i b8 = {fb[j][0], fb[j][1], fb[j][2], fb[j][3], 0, 0, 0, 0}, a8 = {fa[i][0], fa[i][1], fa[i][2], fa[i][3], 0, 0, 0, 0};
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b8, a8, acc[i][j], FMT_FP4, FMT_FP4, 0, scb[j], 0, sca[i]);
+            }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));   // pin the cluster to this phase
+        __builtin_amdgcn_s_setprio(0);
+        gnk_gemm::pp2_phase_barrier();
+        // ---- LOAD phase
+        if (s + 1 < ns) load_frags(s + 1);
+        if (s + 4 < ns) {
+            issue_stage(s + 4);
+            // stages s+3, s+4 may stay in flight, s+2 has landed: 8 loads, 9 when one of the two brought a panel (s % 4 in {0, 1})
+            if ((s & 3) < 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        gnk_gemm::pp2_phase_barrier();
+    }
+    if (wm == 0) gnk_gemm::pp2_phase_barrier();   // pay the stagger back so barrier counts match
+
+    const int64_t mwave = m0 + wm * 128, nwave = n0 + wn * 64;
+    if (mp.bias) {
+        const int64_t ncol = nwave + 4 * (lane >> 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int64_t n = ncol + 16 * j + q;
+                n = n < p.N ? n : p.N - 1;
+                const float b = gnk_load_scalar_rt(mp.bias, mp.bias_dtype, n);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i][j][q] = __fadd_rn(acc[i][j][q], b);
+            }
+    }
+    __syncthreads();
+    v4f(*no_accf)[1] = nullptr;
+    gnk_gemm::run_epilogue<Mx256Cfg>(p, acc, no_accf, smem, wave, lane, mwave, nwave);
+}
+
 // any sizes / alignment (k % 32 == 0 by format): one output per thread, blocks in ascending order
 __global__ void __launch_bounds__(256) mxfp4_generic_kernel(const MxParams mp) {
     const GemmParams &p = mp.g;
@@ -219,6 +353,25 @@ extern "C" int gnk_mxfp4_mm(const void *A, const void *B, void *C, int out_dtype
     const bool fast = K >= 256 && K % 256 == 0 && al(A, 16) && al(B, 16) && lda % 16 == 0 && ldb % 16 == 0 && al(scale_A, 8) && al(scale_B, 8) &&
                       ldsa % 8 == 0 && ldsb % 8 == 0 && M < (1LL << 31) && N < (1LL << 31) && lda * 256 < (1LL << 31) && ldb * 256 < (1LL << 31) &&
                       ((M + 127) / 128) * ((N + 127) / 128) < (1LL << 31);
+    // 256 x 256 ping-pong kernel once its tiles fill most of the chip (as plan_gemm does for int8 / fp8); a scale panel is 16 bytes per row: K % 512 == 0
+    const bool fast256 = K >= 512 && K % 512 == 0 && al(A, 16) && al(B, 16) && lda % 16 == 0 && ldb % 16 == 0 && al(scale_A, 16) && al(scale_B, 16) &&
+                         ldsa % 16 == 0 && ldsb % 16 == 0 && M < (1LL << 31) && N < (1LL << 31) && lda * 256 < (1LL << 31) && ldb * 256 < (1LL << 31);
+    const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
+    const int forced = mp.g.debug & 256 ? 1 : mp.g.debug & 512 ? 2 : 0;   // debug flags (A/B timing): 256 = force the 128^2 kernel, 512 = force the 256^2 kernel
+    if (fast256 && tiles256 < (1LL << 31) && forced != 1 && (forced == 2 || !fast || tiles256 * 5 >= (int64_t)gnk_num_cus() * 4)) {
+        mp.g.grid_m = (int)((M + 255) / 256);
+        mp.g.grid_n = (int)((N + 255) / 256);
+        static bool attr256[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return gnk_fail(GNK_ERR_LAUNCH, "mxfp4_mm: no current HIP device");
+        if (!attr256[dev]) {
+            if (hipFuncSetAttribute((const void *)mxfp4_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MX256_LDS) != hipSuccess)
+                return gnk_fail(GNK_ERR_LAUNCH, "mxfp4_mm: cannot reserve %d bytes of LDS", MX256_LDS);
+            attr256[dev] = true;
+        }
+        hipLaunchKernelGGL(mxfp4_256_kernel, dim3((unsigned)(mp.g.grid_m * mp.g.grid_n)), dim3(512), MX256_LDS, st, mp);
+        return gnk_check_launch("mxfp4_mm (256 x 256)");
+    }
     if (fast) {
         mp.g.grid_m = (int)((M + 127) / 128);
         mp.g.grid_n = (int)((N + 127) / 128);

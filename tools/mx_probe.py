@@ -16,10 +16,12 @@ for S in (1024, 2048, 4096, 8192):
     sB = torch.randint(120, 134, (S, S // 32), dtype=torch.uint8, device="cuda").view(mx.E8M0)
     t = timeit(lambda: mx.mxfp4_mm(A, B, sA, sB))
     from gn_kernels import _cabi
-    _cabi.load().gnk_set_debug_flags(128)
-    t_noscale = timeit(lambda: mx.mxfp4_mm(A, B, sA, sB))
+    res = []
+    for flags in (128, 1024, 128 + 1024, 256):
+        _cabi.load().gnk_set_debug_flags(flags)
+        res.append(f"flags {flags}: {timeit(lambda: mx.mxfp4_mm(A, B, sA, sB)):7.1f} us")
     _cabi.load().gnk_set_debug_flags(0)
-    print(f"   (without per-step scale loads: {t_noscale:8.1f} us)")
+    print("   ablations (128 = no scale DMA, 1024 = no scale LDS reads, 256 = 128^2 kernel): " + " | ".join(res))
     print(f"mxfp4_mm {S}^3: {t:8.1f} us  {2 * S ** 3 / t / 1e6:7.0f} TFLOP/s  ({2 * S ** 3 / t / 1e6 / 10066 * 100:4.1f} % of 10.07 PF)", flush=True)
 for shape in ((4096, 4096), (16384, 8192)):
     x = torch.randn(shape, device="cuda").bfloat16()

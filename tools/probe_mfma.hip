@@ -30,9 +30,41 @@ template <int KIND> __global__ void __launch_bounds__(512) k(const int *in, int 
         } else if constexpr (KIND == 2) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { cf[j & 3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, cf[j & 3], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f); }
-        } else {
+        } else if constexpr (KIND == 3) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { df[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, df[j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f); }
+        } else if constexpr (KIND == 4) {   // FP4 operands (cbsz = blgp = 4), unit scales
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { df[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, df[j], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f); }
+        } else if constexpr (KIND == 5) {   // FP4 operands, per-lane scale bytes
+            const int sa = 120 + (lane & 7), sb = 124 + ((lane >> 3) & 7);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { df[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, df[j], 4, 4, 0, sa, 0, sb); }
+        } else if constexpr (KIND == 7) {   // FP4 operands, DISTINCT operand registers per MFMA (2 a-fragments x 4 b-fragments), per-lane scales
+            const int sa = 120 + (lane & 7), sb = 124 + ((lane >> 3) & 7);
+            v8i a2 = {a[4], a[5], a[6], a[7], 0, 0, 0, 0}, b2 = {b[4], b[5], b[6], b[7], 0, 0, 0, 0};
+            v8i b3 = {b[1], b[2], b[3], b[4], 0, 0, 0, 0}, b4v = {b[5], b[6], b[7], b[0], 0, 0, 0, 0};
+            df[0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, df[0], 4, 4, 0, sa, 0, sb);
+            df[1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b2, df[1], 4, 4, 0, sa, 0, sb + 1);
+            df[2] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b3, df[2], 4, 4, 0, sa, 0, sb + 2);
+            df[3] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b4v, df[3], 4, 4, 0, sa, 0, sb + 3);
+            df[4] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a2, b, df[4], 4, 4, 0, sa + 1, 0, sb);
+            df[5] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a2, b2, df[5], 4, 4, 0, sa + 1, 0, sb + 1);
+            df[6] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a2, b3, df[6], 4, 4, 0, sa + 1, 0, sb + 2);
+            df[7] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a2, b4v, df[7], 4, 4, 0, sa + 1, 0, sb + 3);
+        } else if constexpr (KIND == 8) {   // int8 16x16x64 with the same distinct-operand pattern
+            v4i a2 = {a[4], a[5], a[6], a[7]}, b2 = {b[4], b[5], b[6], b[7]}, b3 = {b[1], b[2], b[3], b[4]}, b4v = {b[5], b[6], b[7], b[0]};
+            di[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a4, b4, di[0], 0, 0, 0);
+            di[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a4, b2, di[1], 0, 0, 0);
+            di[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a4, b3, di[2], 0, 0, 0);
+            di[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a4, b4v, di[3], 0, 0, 0);
+            di[4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b4, di[4], 0, 0, 0);
+            di[5] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, di[5], 0, 0, 0);
+            di[6] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b3, di[6], 0, 0, 0);
+            di[7] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b4v, di[7], 0, 0, 0);
+        } else {                            // FP4 operands, 32 x 32 x 64
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { cf[j & 3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, cf[j & 3], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f); }
         }
     }
     const long long t1 = __builtin_amdgcn_s_memtime();
@@ -50,8 +82,8 @@ int main() {
     for (int zero = 0; zero < 2; ++zero) {
         for (int i = 0; i < 1024; ++i) h[i] = zero ? 0 : (rand() * 2654435761u) ^ rand();
         CHECK(hipMemcpy(in, h, 4096, hipMemcpyHostToDevice));
-        const char *names[4] = {"i32_32x32x32_i8", "i32_16x16x64_i8", "scale_f32_32x32x64_f8", "scale_f32_16x16x128_f8"};
-        for (int kind = 0; kind < 4; ++kind)
+        const char *names[9] = {"i32_32x32x32_i8", "i32_16x16x64_i8", "scale_f32_32x32x64_f8", "scale_f32_16x16x128_f8", "scale_16x16x128_fp4", "scale_16x16x128_fp4_sc", "scale_32x32x64_fp4", "fp4_16x16x128_distinct", "i8_16x16x64_distinct"};
+        for (int kind = 0; kind < 9; ++kind)
             for (int waves = 4; waves <= 8; waves += 4)
                 for (int blocks = 1; blocks <= 256; blocks *= 256) {
                     const int iters = 20000;
@@ -62,7 +94,12 @@ int main() {
                         case 0: hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(64 * waves), 0, 0, in, out, cyc, iters); break;
                         case 1: hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(64 * waves), 0, 0, in, out, cyc, iters); break;
                         case 2: hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(64 * waves), 0, 0, in, out, cyc, iters); break;
-                        default: hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(64 * waves), 0, 0, in, out, cyc, iters); break;
+                        case 3: hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(64 * waves), 0, 0, in, out, cyc, iters); break;
+                        case 4: hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(64 * waves), 0, 0, in, out, cyc, iters); break;
+                        case 5: hipLaunchKernelGGL(k<5>, dim3(blocks), dim3(64 * waves), 0, 0, in, out, cyc, iters); break;
+                        case 7: hipLaunchKernelGGL(k<7>, dim3(blocks), dim3(64 * waves), 0, 0, in, out, cyc, iters); break;
+                        case 8: hipLaunchKernelGGL(k<8>, dim3(blocks), dim3(64 * waves), 0, 0, in, out, cyc, iters); break;
+                        default: hipLaunchKernelGGL(k<6>, dim3(blocks), dim3(64 * waves), 0, 0, in, out, cyc, iters); break;
                         }
                         CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
                     }
