@@ -476,6 +476,21 @@ template <class Cfg> struct TileScaleIdx {
             for (int j = 0; j < NTL; ++j) rb[j] = gnk_load_raw<GNK_BF16>(p.s1, boff[j] + bt);
         }
     }
+    // B side alone (the A side comes from the LDS panel, see gemm_kernel)
+    __device__ __forceinline__ void load_raw_b(const GemmParams &p, int t, unsigned (&rb)[NTL]) const {
+        const int bt = t * bstep;
+        if (p.scale_dtype == GNK_F32) {
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) rb[j] = gnk_load_raw<GNK_F32>(p.s1, boff[j] + bt);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) rb[j] = gnk_load_raw<GNK_BF16>(p.s1, boff[j] + bt);
+        }
+    }
+    static __device__ __forceinline__ void convert_b(const GemmParams &p, const unsigned (&rb)[NTL], float (&sbv)[NTL]) {
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) sbv[j] = gnk_raw_to_f32_rt(rb[j], p.scale_dtype);
+    }
     static __device__ __forceinline__ void convert(const GemmParams &p, const unsigned (&ra)[MT], const unsigned (&rb)[NTL], float (&sav)[MT], float (&sbv)[NTL]) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) sav[i] = gnk_raw_to_f32_rt(ra[i], p.scale_dtype);
@@ -547,14 +562,44 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
             for (int j = 0; j < NTL; ++j) accf[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
     }
 
+    // Tile scales.  B side: the lane's NTL scale blocks, fetched one K-step ahead (usually one broadcast value: QN >= the tile).
+    // A side: per-lane fetches of sA[m / QM, t] touch 16 rows per load instruction (row-major sA: 16 cache lines for 32 bytes)
+    // and cost 15-25 % of the kernel; instead the workgroup stages a PANEL of its BM rows x 8 K-blocks in LDS (fp32, [step][row])
+    // with one element per thread and load, k fastest (coalesced for row-major sA), once per 8 steps.
+    constexpr int TS_STEPS = 8, TS_PE = Cfg::EPI == EPI_TILE ? Cfg::BM * TS_STEPS / Cfg::NT : 1;
+    const int nk = (int)(p.K / GNK_BK);
     TileScaleIdx<Cfg> ts;
-    unsigned raw_a[Cfg::EPI == EPI_TILE ? MT : 1], raw_b[Cfg::EPI == EPI_TILE ? NTL : 1];
+    unsigned raw_b[Cfg::EPI == EPI_TILE ? NTL : 1], praw[TS_PE];
+    int poff[TS_PE];
+    float *const panel = (float *)(smem + Cfg::LDS_BYTES);
+    auto panel_fetch = [&](int pn) {
+#pragma unroll
+        for (int u = 0; u < TS_PE; ++u) {
+            const int tt = pn * TS_STEPS + (((int)threadIdx.x + Cfg::NT * u) % TS_STEPS);
+            praw[u] = tt < nk ? gnk_load_raw_rt(p.s0, p.scale_dtype, poff[u] + tt * (int)p.ssak) : 0u;
+        }
+    };
+    auto panel_store = [&]() {
+#pragma unroll
+        for (int u = 0; u < TS_PE; ++u) {
+            const int e = (int)threadIdx.x + Cfg::NT * u;
+            *(GNK_LDS float *)(GNK_LDS char *)((char *)panel + ((e % TS_STEPS) * Cfg::BM + e / TS_STEPS) * 4) = gnk_raw_to_f32_rt(praw[u], p.scale_dtype);
+        }
+    };
     if constexpr (Cfg::EPI == EPI_TILE) {
         ts.init(p, mrow, ncol);
-        if (p.K >= GNK_BK) ts.load_raw(p, 0, raw_a, raw_b);
+#pragma unroll
+        for (int u = 0; u < TS_PE; ++u) {
+            int64_t m = m0 + ((int)threadIdx.x + Cfg::NT * u) / TS_STEPS;
+            m = m < p.M ? m : p.M - 1;
+            poff[u] = (int)(((unsigned)m / (unsigned)p.QM) * (unsigned)p.ssam);
+        }
+        if (nk > 0) {
+            ts.load_raw_b(p, 0, raw_b);
+            panel_fetch(0);
+        }
     }
 
-    const int nk = (int)(p.K / GNK_BK);
     if (nk > 0) {
         sa.issue(As0, wave);
         sb.issue(Bs0, wave);
@@ -568,8 +613,17 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
         float sav[Cfg::EPI == EPI_TILE ? MT : 1];
         float sbv[Cfg::EPI == EPI_TILE ? NTL : 1];
         if constexpr (Cfg::EPI == EPI_TILE) {
-            TileScaleIdx<Cfg>::convert(p, raw_a, raw_b, sav, sbv);
-            if (t + 1 < nk) ts.load_raw(p, t + 1, raw_a, raw_b);
+            const int tsi = t % TS_STEPS;
+            if (tsi == 0) {            // the panel of steps t .. t + 7 was fetched during step t - 1 (or before the loop)
+                panel_store();
+                __syncthreads();
+            }
+            TileScaleIdx<Cfg>::convert_b(p, raw_b, sbv);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                sav[i] = *(const GNK_LDS float *)(const GNK_LDS char *)((const char *)panel + (tsi * Cfg::BM + wm * Cfg::WTM + 16 * i + (lane & 15)) * 4);
+            if (t + 1 < nk) ts.load_raw_b(p, t + 1, raw_b);
+            if (tsi == TS_STEPS - 1 && t + 1 < nk) panel_fetch((t + 1) / TS_STEPS);
         }
 
         const int cur = t & 1;
@@ -606,7 +660,7 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
 }
 
 template <class Cfg> int launch(const GemmParams &p0, hipStream_t st) {
-    constexpr int LDS_TOTAL = Cfg::LDS_BYTES + ScalePrefetch<Cfg::BM, Cfg::BN, Cfg::NT, Cfg::EPI>::BYTES;
+    constexpr int LDS_TOTAL = Cfg::LDS_BYTES + ScalePrefetch<Cfg::BM, Cfg::BN, Cfg::NT, Cfg::EPI>::BYTES + (Cfg::EPI == EPI_TILE ? Cfg::BM * 8 * 4 : 0);
     GemmParams p = p0;
     p.grid_m = (int)((p.M + Cfg::BM - 1) / Cfg::BM);
     p.grid_n = (int)((p.N + Cfg::BN - 1) / Cfg::BN);

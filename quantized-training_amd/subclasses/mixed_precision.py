@@ -15,6 +15,7 @@ results are bit-identical to the reference's.
 """
 from __future__ import annotations
 
+import threading
 from typing import NamedTuple
 
 import torch
@@ -121,6 +122,7 @@ _CACHE_SLOTS = 4
 _cache_enabled = True
 _fused_enabled = True
 _cache: dict = {}
+_cache_lock = threading.Lock()        # forward runs on the caller's thread, backward on the autograd engine's
 
 
 def set_quantize_plan(*, cache: bool | None = None, fused: bool | None = None) -> tuple[bool, bool]:
@@ -129,10 +131,16 @@ def set_quantize_plan(*, cache: bool | None = None, fused: bool | None = None) -
     old = (_cache_enabled, _fused_enabled)
     if cache is not None:
         _cache_enabled = cache
-        _cache.clear()
+        clear_quantize_cache()
     if fused is not None:
         _fused_enabled = fused
     return old
+
+
+def clear_quantize_cache() -> None:
+    """Drop the cached int8 copies (and the activations they pin); e.g. at the end of a step when memory is tight."""
+    with _cache_lock:
+        _cache.clear()
 
 
 def _key(kind: str, t: Tensor):
@@ -142,16 +150,18 @@ def _key(kind: str, t: Tensor):
 def _cache_get(kind: str, t: Tensor, sr: bool):
     if sr or not _cache_enabled:
         return None
-    hit = _cache.get(_key(kind, t))
+    with _cache_lock:
+        hit = _cache.get(_key(kind, t))
     return hit[1] if hit is not None else None
 
 
 def _cache_put(kind: str, t: Tensor, sr: bool, value):
     if sr or not _cache_enabled:
         return
-    while len(_cache) >= 2 * _CACHE_SLOTS:
-        _cache.pop(next(iter(_cache)))                   # dicts keep insertion order: drop the oldest
-    _cache[_key(kind, t)] = (t, value)                   # holding t pins its memory, so the key cannot alias a new tensor
+    with _cache_lock:
+        while len(_cache) >= 2 * _CACHE_SLOTS:
+            _cache.pop(next(iter(_cache)))               # dicts keep insertion order: drop the oldest
+        _cache[_key(kind, t)] = (t, value)               # holding t pins its memory, so the key cannot alias a new tensor
 
 
 def _plan_ok(*ts: Tensor) -> bool:
