@@ -183,6 +183,27 @@ int gnk_mxfp4_mm(const void *A, const void *B, void *C, int out_dtype, const voi
                  int64_t ldsa, int64_t ldsb, void *stream);
 
 /*
+ * BitNet b1.58 weight path, SURVEY.md section 8f rank 4 (the COL_SCALE_SCALAR caller of scaled_mm and its FSDP2 hooks).
+ * All tensors contiguous, walked flat; eager ATen chains in the reference, one HBM-bound kernel each here.
+ *
+ * gnk_bitnet_absmean: out[0] = mean(|f32(x)|) as fp32.  Replaces subclasses/bitnet.py:110-112 (get_bitnet_scale).  Fixed
+ *   summation order (fp32 per lane, fp64 above): deterministic, within 1e-6 relative of any other order.  workspace: at
+ *   least gnk_bitnet_absmean_workspace_bytes() bytes, 8-byte aligned (per-workgroup partial sums; no need to clear it).
+ * gnk_bitnet_quantize_weight: clip(round_half_even(f32(w) / max(scale[0], eps)), -1, 1).  Replaces subclasses/bitnet.py:115-118
+ *   (quantize_bitnet_weight); scale is a DEVICE fp32 scalar (no host sync).  packed = 0: out is numel int8 values; packed = 1:
+ *   out is numel / 4 bytes in the layout of gnk_bitnet_pack_i2, fusing subclasses/bitnet.py:88-89 (fsdp_pre_all_gather).
+ * gnk_bitnet_pack_i2: four consecutive int8 values [a, b, c, d] -> one byte (a << 6) | ((b & 3) << 4) | ((c & 3) << 2) | (d & 3).
+ *   Replaces subclasses/bitnet.py:185-195 (_pack_i2_in_i8; rows are multiples of 4, so the flat walk equals the row-wise one).
+ * gnk_bitnet_unpack_i2: nbytes packed bytes -> 4 * nbytes sign-extended int8 values.  Replaces subclasses/bitnet.py:198-201.
+ */
+size_t gnk_bitnet_absmean_workspace_bytes(void);
+int gnk_bitnet_absmean(const void *x, int x_dtype, int64_t numel, float *out, void *workspace, size_t workspace_bytes, void *stream);
+int gnk_bitnet_quantize_weight(const void *w, int w_dtype, int64_t numel, const float *scale, float eps, void *out, int packed,
+                               void *stream);
+int gnk_bitnet_pack_i2(const void *x, int64_t numel, void *out, void *stream);
+int gnk_bitnet_unpack_i2(const void *x, int64_t nbytes, void *out, void *stream);
+
+/*
  * Test / tuning hook (no reference counterpart): force a GEMM kernel variant for subsequent
  * calls on this thread.  variant < 0 restores the built-in heuristic.  Returns the previous
  * value.  Variants are listed in csrc/gnk_gemm_dispatch.h.

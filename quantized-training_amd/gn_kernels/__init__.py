@@ -3,6 +3,7 @@ HIP kernels behind a C ABI (include/gnk.h).  Public names follow kernels/gn_kern
 the reference; names outside the INT8/FP8 scaled-matmul hot path and its MX extension import fine and raise
 NotImplementedError when called."""
 from . import _cabi
+from . import bitnet  # noqa: F401  (registers the bitnet_* device ops)
 from .fp8 import fp8_mm, scaled_fp8_mm
 from .mm import _triton_mm, int8_mm, scaled_mm
 from .mx import dequantize_mxfp4, mxfp4_mm, pack_block_scales_nv, quantize_mx

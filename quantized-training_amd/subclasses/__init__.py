@@ -1,9 +1,11 @@
 """Tensor subclasses of the quantized-training hot path on MI355X.
 
-In scope (reference subclasses/__init__.py names): the INT8 quantizer, `Int8LinearWeight` and the
-INT8 mixed-precision weight.  BitNet and INT4 weight-only subclasses are outside the scaled INT8 /
-FP8 matmul path; their names import and raise when used.
+In scope (reference subclasses/__init__.py names): the INT8 quantizer, `Int8LinearWeight`, the INT8
+mixed-precision weight and the BitNet training weight (the scalar-column-scale caller of `scaled_mm`,
+SURVEY.md section 8f rank 4).  The INT4 weight-only subclass is outside the scaled INT8 / FP8 matmul
+path (no INT4 MFMA on CDNA4); its names import and raise when used.
 """
+from .bitnet import BitNetTrainingLinearWeight, convert_bitnet
 from .int8 import Int8LinearWeight, Int8QTConfig, convert_int8_quantized_training, quantize_int8
 from .mixed_precision import MixedPrecisionConfig, MixedPrecisionLinearWeight, convert_mixed_precision
 
@@ -16,8 +18,6 @@ def _out_of_scope(name: str):
     return fn
 
 
-BitNetTrainingLinearWeight = _out_of_scope("BitNetTrainingLinearWeight")
-convert_bitnet = _out_of_scope("convert_bitnet")
 Int4LinearWeight = _out_of_scope("Int4LinearWeight")
 convert_int4_quantized_training = _out_of_scope("convert_int4_quantized_training")
 

@@ -166,7 +166,7 @@ def test_int8_linear_weight_paths(oracle_cpu_ops):
 
 
 def test_out_of_scope_names_import_and_raise():
-    for name in ("convert_bitnet", "convert_int4_quantized_training", "BitNetTrainingLinearWeight", "Int4LinearWeight"):
+    for name in ("convert_int4_quantized_training", "Int4LinearWeight"):
         with pytest.raises(NotImplementedError):
             getattr(subclasses, name)(None)
 
