@@ -140,3 +140,19 @@ def test_fsdp_hook_pair_on_device_and_llama_sized_step():
     before = w._data.clone()
     opt.step()
     assert isinstance(lin.weight, bn.BitNetTrainingLinearWeight) and not torch.equal(lin.weight._data, before)
+
+
+def test_bitnet_training_steps_learn():
+    torch.manual_seed(0)
+    model = bn.convert_bitnet(nn.Sequential(nn.Linear(256, 512), nn.GELU(), nn.Linear(512, 256)).to(BF).to(DEV))
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    x = torch.randn(512, 256, device=DEV, dtype=BF)
+    tgt = torch.randn(512, 256, device=DEV, dtype=BF)
+    losses = []
+    for _ in range(30):
+        loss = (model(x).float() - tgt.float()).square().mean()
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0] * 0.95, losses

@@ -56,7 +56,7 @@ def get_loss(model, tokens, labels):   # llm_pretrain.py:30-36
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="470m", choices=list(MODELS))
-    ap.add_argument("--quantize", default="mixed_precision", choices=["none", "mixed_precision", "int8"])
+    ap.add_argument("--quantize", default="mixed_precision", choices=["none", "mixed_precision", "int8", "bitnet"])
     ap.add_argument("--batch_size", type=int, default=4, help="GLOBAL batch (split over ranks as llm_pretrain.py:93,151)")
     ap.add_argument("--seq_len", type=int, default=2048)
     ap.add_argument("--steps", type=int, default=10)
@@ -102,6 +102,10 @@ def main():
         from subclasses import convert_int8_quantized_training
 
         convert_int8_quantized_training(model.model)
+    elif args.quantize == "bitnet":
+        from subclasses import convert_bitnet
+
+        convert_bitnet(model.model)                   # train_utils.py's extra RMSNorm in front of every Linear is model surgery, not part of this path
     n_params = sum(p.numel() for p in model.parameters())
     if world > 1:
         from torch.nn.parallel import DistributedDataParallel as DDP
@@ -147,7 +151,8 @@ def main():
         out = {
             "metric": "Llama INT8 mixed-precision training tok/s", "value": round(toks / dt, 1), "unit": "tok/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "strong", "dtype": "bf16 weights/activations; int8 MFMA in the Linear fwd / grad-input / grad-weight" if args.quantize != "none" else "bf16",
+            "scaling": "strong", "dtype": {"none": "bf16", "bitnet": "bf16 weights/activations; int8 x ternary MFMA in the Linear fwd, bf16 bwd"}.get(
+                args.quantize, "bf16 weights/activations; int8 MFMA in the Linear fwd / grad-input / grad-weight"),
             "data": "synthetic tokens, random-init weights",
             "config": {"workload": f"llama-{args.model} {'(ASSUMED 1.1B shape: 2048/5632/22/32)' if args.model == '1b' else ''} global_batch {args.batch_size} x seq_len {args.seq_len}, "
                                    f"quantize={args.quantize}, AdamW, {'DDP x%d (RCCL all-reduce)' % world if world > 1 else 'single GPU'}",
