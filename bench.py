@@ -276,6 +276,17 @@ def main():
                 t_mm = time_kernel_graph(lambda: mx.mxfp4_mm(A4, B4, s4a, s4b), per_graph=10)
                 nxt[f"mxfp4_mm {S}^3"] = {"us": round(t_mm * 1e3, 1), "TFLOP/s": round(2 * S ** 3 / (t_mm * 1e-3) * 1e-12, 1),
                                           "frac_of_fp4_dense_peak_10066": round(2 * S ** 3 / (t_mm * 1e-3) * 1e-12 / 10066.0, 4)}
+                del A4, B4, s4a, s4b
+                from gn_kernels import bitnet as bop
+
+                w = (torch.randn(2 * S, 2 * S, device=dev) * 0.02).bfloat16()      # BitNet weight path, 8192^2 bf16
+                sc = bop.bitnet_absmean(w)
+                t_am = time_kernel_graph(lambda: bop.bitnet_absmean(w), per_graph=10)
+                t_qp = time_kernel_graph(lambda: bop.bitnet_quantize_weight(w, sc, packed=True), per_graph=10)
+                nxt[f"bitnet {2 * S}x{2 * S} bf16"] = {"absmean_us": round(t_am * 1e3, 1), "absmean_GB/s": round(2 * w.numel() / (t_am * 1e-3) * 1e-9, 1),
+                                                     "quantize+pack2bit_us": round(t_qp * 1e3, 1),
+                                                     "quantize+pack2bit_GB/s": round(2.25 * w.numel() / (t_qp * 1e-3) * 1e-9, 1)}
+                del w
             except Exception as exc:   # detail only: never a reason to lose the bench line
                 nxt["error"] = f"{type(exc).__name__}: {exc}"
             out["detail_next_rows"] = nxt
