@@ -126,12 +126,13 @@ static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
     }
 }
 
-/* U[0,1) with 24 random bits for logical element index idx */
+/* U[0,1) with 24 random bits for logical element index idx: word (e & 3) of the Philox block with counter e >> 2,
+ * e = idx + offset (four elements share one block; the HIP kernels draw them together). */
 float orc_sr_uniform(uint64_t seed, uint64_t offset, uint64_t idx) {
-    uint64_t ctr = idx + offset;
+    uint64_t e = idx + offset, ctr = e >> 2;
     uint32_t c[4] = { (uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u };
     philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    return (float)(c[0] >> 8) * (1.0f / 16777216.0f);
+    return (float)(c[e & 3] >> 8) * (1.0f / 16777216.0f);
 }
 
 /* ------------------------------------------------------------------ quantize_int8

@@ -141,14 +141,31 @@ __device__ __forceinline__ void gnk_philox4x32_10(unsigned c[4], unsigned k0, un
     }
 }
 
-// U[0,1) for logical element `idx` (24 random bits), one Philox block per element.
+// Stochastic-rounding stream: logical element `idx` of a call takes word (e & 3) of the Philox4x32-10 block with counter e >> 2,
+// e = idx + offset -- FOUR elements per block (one block per element made the SR quantize passes VALU-bound: ~70 integer
+// instructions per element, +104 ms on a Llama-1B step).  U[0,1) with 24 random bits.
+__device__ __forceinline__ float gnk_sr_bits_to_uniform(unsigned w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
+
 __device__ __forceinline__ float gnk_sr_uniform(unsigned long long seed, unsigned long long offset,
                                                 unsigned long long idx) {
-    unsigned long long ctr = idx + offset;
+    const unsigned long long e = idx + offset, ctr = e >> 2;
     unsigned c[4] = {(unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u};
     gnk_philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
-    return (float)(c[0] >> 8) * (1.0f / 16777216.0f);
+    const unsigned k = (unsigned)e & 3u;
+    return gnk_sr_bits_to_uniform(k == 0 ? c[0] : k == 1 ? c[1] : k == 2 ? c[2] : c[3]);
 }
+
+// the four uniforms of elements idx0 .. idx0 + 3; the caller guarantees (idx0 + offset) % 4 == 0
+__device__ __forceinline__ void gnk_sr_uniform4(unsigned long long seed, unsigned long long offset, unsigned long long idx0, float (&u)[4]) {
+    const unsigned long long ctr = (idx0 + offset) >> 2;
+    unsigned c[4] = {(unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u};
+    gnk_philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u[k] = gnk_sr_bits_to_uniform(c[k]);
+}
+
+// stochastic rounding of an already divided value: floor(v + u), clipped (subclasses/int8.py:21,25)
+__device__ __forceinline__ int gnk_sr_clip_i8(float v, float u) { return (int)fminf(fmaxf(floorf(v + u), -128.0f), 127.0f); }
 
 // One quantization step of subclasses/int8.py:18-25 given the divisor max(scale, eps).
 template <bool SR>

@@ -62,8 +62,18 @@ __device__ __forceinline__ void quant_chunk(const v4i &raw, const GnkDivisor &dv
     unpack16<DT>(raw, f);
     int qi[VEC];
     if constexpr (SR) {
+        if (((idx0 + offset) & 3ull) == 0) {      // the usual case (rows of a multiple of 4 elements): one Philox block per 4 elements
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) qi[j] = gnk_quant_one<true>(f[j], dv.d, seed, offset, idx0 + j);
+            for (int g = 0; g < VEC / 4; ++g) {
+                float u[4];
+                gnk_sr_uniform4(seed, offset, idx0 + 4 * g, u);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) qi[4 * g + k] = gnk_sr_clip_i8(fast ? dv.quot(f[4 * g + k]) : f[4 * g + k] / dv.d, u[k]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) qi[j] = gnk_quant_one<true>(f[j], dv.d, seed, offset, idx0 + j);
+        }
     } else {
         if (fast) {
 #pragma unroll
@@ -383,39 +393,68 @@ col_quant_kernel(const char *__restrict__ x, int8_t *__restrict__ q, void *__res
         fast = fast && dv[j].ok();
         if (blockIdx.y == 0 && rl == 0) gnk_store_scalar_rt(scale, DT, col0 + j, s);
     }
-    // all of this thread's rows are loaded before the first is used: 16 x 16 B in flight per lane
+    // all of this thread's rows are loaded before the first is used: 16 x 16 B in flight per lane.  Row of slot i: interleaved
+    // over the 8 row-lanes (i * 8 + rl), except under stochastic rounding, where a thread takes NIT CONSECUTIVE rows: logical
+    // element indices of the (Q, P) view run along the rows, and four consecutive ones share a Philox block.
     constexpr int NIT = COL_PB / 8;
+    auto row_of = [&](int i) -> int64_t { return SR ? row0 + rl * NIT + i : row0 + i * 8 + rl; };
+    auto store_row = [&](int64_t row, const int (&qi)[VEC]) {
+        if constexpr (VEC == 8) {
+            v2i o = {(int)pack4_i8(qi[0], qi[1], qi[2], qi[3]), (int)pack4_i8(qi[4], qi[5], qi[6], qi[7])};
+            if constexpr (NT) __builtin_nontemporal_store(o, (v2i *)(q + row * ldq + col0));
+            else *(v2i *)(q + row * ldq + col0) = o;
+        } else {
+            *(unsigned *)(q + row * ldq + col0) = pack4_i8(qi[0], qi[1], qi[2], qi[3]);
+        }
+    };
     v4i raw[NIT];
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-        const int64_t row = row0 + i * 8 + rl;
+        const int64_t row = row_of(i);
         raw[i] = (v4i){0, 0, 0, 0};
         if (row < P) raw[i] = *(const v4i *)(x + row * ld_bytes + col0 * (16 / VEC));
     }
+    if constexpr (SR) {
+        const bool aligned = ((P | (int64_t)offset) & 3) == 0;      // every 4-row group then starts a Philox block
 #pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-        const int64_t row = row0 + i * 8 + rl;
-        if (row < P) {
-            float f[VEC];
-            unpack16<DT>(raw[i], f);
-            int qi[VEC];
-            if constexpr (SR) {
+        for (int g = 0; g < NIT / 4; ++g) {
+            float f[4][VEC];
+            int qi[4][VEC];
 #pragma unroll
-                for (int j = 0; j < VEC; ++j)   // logical element (r = col, c = row) of the (Q, P) view
-                    qi[j] = gnk_quant_one<true>(f[j], dv[j].d, seed, offset, (unsigned long long)((col0 + j) * P + row));
-            } else if (fast) {
+            for (int k = 0; k < 4; ++k) unpack16<DT>(raw[4 * g + k], f[k]);
+            const int64_t r0 = row_of(4 * g);
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) qi[j] = gnk_rne_clip_i8(dv[j].quot(f[j]));
-            } else {
+            for (int j = 0; j < VEC; ++j) {
+                const unsigned long long idx0 = (unsigned long long)((col0 + j) * P + r0);   // logical element (r = col, c = row) of the (Q, P) view
+                float u[4];
+                if (aligned) gnk_sr_uniform4(seed, offset, idx0, u);
+                else {
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) qi[j] = gnk_rne_clip_i8(f[j] / dv[j].d);
+                    for (int k = 0; k < 4; ++k) u[k] = gnk_sr_uniform(seed, offset, idx0 + k);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) qi[k][j] = gnk_sr_clip_i8(fast ? dv[j].quot(f[k][j]) : f[k][j] / dv[j].d, u[k]);
             }
-            if constexpr (VEC == 8) {
-                v2i o = {(int)pack4_i8(qi[0], qi[1], qi[2], qi[3]), (int)pack4_i8(qi[4], qi[5], qi[6], qi[7])};
-                if constexpr (NT) __builtin_nontemporal_store(o, (v2i *)(q + row * ldq + col0));
-                else *(v2i *)(q + row * ldq + col0) = o;
-            } else {
-                *(unsigned *)(q + row * ldq + col0) = pack4_i8(qi[0], qi[1], qi[2], qi[3]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (r0 + k < P) store_row(r0 + k, qi[k]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int64_t row = row_of(i);
+            if (row < P) {
+                float f[VEC];
+                unpack16<DT>(raw[i], f);
+                int qi[VEC];
+                if (fast) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) qi[j] = gnk_rne_clip_i8(dv[j].quot(f[j]));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) qi[j] = gnk_rne_clip_i8(f[j] / dv[j].d);
+                }
+                store_row(row, qi);
             }
         }
     }

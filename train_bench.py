@@ -57,6 +57,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="470m", choices=list(MODELS))
     ap.add_argument("--quantize", default="mixed_precision", choices=["none", "mixed_precision", "int8", "bitnet"])
+    ap.add_argument("--quantize_kwargs", default="{}", help='JSON, as llm_pretrain.py:45: MixedPrecisionConfig / Int8QTConfig fields, e.g. \'{"stochastic_rounding": true}\'')
     ap.add_argument("--batch_size", type=int, default=4, help="GLOBAL batch (split over ranks as llm_pretrain.py:93,151)")
     ap.add_argument("--seq_len", type=int, default=2048)
     ap.add_argument("--steps", type=int, default=10)
@@ -94,14 +95,15 @@ def main():
         from gn_kernels import _cabi
 
         _cabi.load().gnk_set_debug_flags(args.gnk_debug_flags)
+    qkw = json.loads(args.quantize_kwargs)
     if args.quantize == "mixed_precision":
-        from subclasses import convert_mixed_precision
+        from subclasses import MixedPrecisionConfig, convert_mixed_precision
 
-        convert_mixed_precision(model.model)          # llm_pretrain.py:122 (lm_head stays bf16 unless --quantize_lm_head)
+        convert_mixed_precision(model.model, config=MixedPrecisionConfig(**qkw))   # llm_pretrain.py:122 (lm_head stays bf16 unless --quantize_lm_head)
     elif args.quantize == "int8":
-        from subclasses import convert_int8_quantized_training
+        from subclasses import Int8QTConfig, convert_int8_quantized_training
 
-        convert_int8_quantized_training(model.model)
+        convert_int8_quantized_training(model.model, config=Int8QTConfig(**qkw))
     elif args.quantize == "bitnet":
         from subclasses import convert_bitnet
 
@@ -155,7 +157,7 @@ def main():
                 args.quantize, "bf16 weights/activations; int8 MFMA in the Linear fwd / grad-input / grad-weight"),
             "data": "synthetic tokens, random-init weights",
             "config": {"workload": f"llama-{args.model} {'(ASSUMED 1.1B shape: 2048/5632/22/32)' if args.model == '1b' else ''} global_batch {args.batch_size} x seq_len {args.seq_len}, "
-                                   f"quantize={args.quantize}, AdamW, {'DDP x%d (RCCL all-reduce)' % world if world > 1 else 'single GPU'}",
+                                   f"quantize={args.quantize}{' ' + args.quantize_kwargs if qkw else ''}, AdamW, {'DDP x%d (RCCL all-reduce)' % world if world > 1 else 'single GPU'}",
                        "params": n_params, "body_linear_weights": lin},
             "body_linear_TOPS": round(6 * args.batch_size * args.seq_len * lin * args.steps / dt * 1e-12, 1),
             "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)],
