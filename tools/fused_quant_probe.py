@@ -36,7 +36,7 @@ def main():
         t_cg = graph_time(lambda: qmod.quantize_int8_colwise_given(x, cm))
         mb = R * C / 1e6
         print(f"{R}x{C}: separate row {t_row:7.1f} + col {t_col:7.1f} = {t_row + t_col:7.1f} us | fused row+colmax {t_rc:7.1f} + col-given {t_cg:7.1f} = {t_rc + t_cg:7.1f} us"
-              f" | {6 * mb / (t_rc + t_cg) / 1e3:5.2f} TB/s algorithmic (6 B/elem)", flush=True)
+              f" | {6 * mb / (t_rc + t_cg):5.2f} TB/s algorithmic (6 B/elem)", flush=True)
 
 
 if __name__ == "__main__":
