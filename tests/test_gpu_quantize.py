@@ -94,10 +94,20 @@ def test_non_dense_strides_and_nd_inputs():
     assert qe.shape == (0, 16) and se.shape == (0, 1)
 
 
-@pytest.mark.parametrize("shape,dim", [((64, 512), 1), ((256, 128), 0), ((9, 33), 1)])
+@pytest.mark.parametrize("shape,dim", [((64, 512), 1), ((256, 128), 0), ((9, 33), 1),
+                                       ((130, 256), 0),      # column pass whose 4-row groups do not start a Philox block (P % 4 != 0)
+                                       ((1000, 512), 0),     # column pass with a ragged last row slab
+                                       ((3, 16384), 1),      # rows too long for the register-resident kernel (two-pass kernel)
+                                       ((33, 8192), 1)])
 def test_stochastic_rounding_bit_exact_vs_oracle_philox(shape, dim):
+    """Four elements share a Philox block (word e & 3 of block e >> 2): the kernels draw them together where a thread holds
+    four consecutive logical elements and fall back to per-element draws elsewhere -- same stream either way."""
     torch.manual_seed(1234)
-    _check_vs_oracle(torch.randn(shape).bfloat16(), dim, sr=True)
+    for dt in (torch.bfloat16, torch.float32):
+        _check_vs_oracle(torch.randn(shape).to(dt), dim, sr=True)
+    q_before = qmod._sr_calls
+    _check_vs_oracle(torch.randn(shape).bfloat16(), dim, sr=True)      # a later call: another offset, still the oracle's stream
+    assert qmod._sr_calls == q_before + 1
 
 
 def test_stochastic_rounding_is_unbiased_like_the_reference():
