@@ -223,22 +223,37 @@ quant_rowwise_colmax_kernel(const char *__restrict__ x, int8_t *__restrict__ q, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) cm[i][j] = 0u;
 
-    v4i raw[NCH], nxt[NCH];
+    // The next row is prefetched while this one is processed, except for the widest rows: three row-sized register sets (row,
+    // next row, column maxima: 144 registers at NCH = 12) spilled at the 128 registers that four waves per SIMD leave; there
+    // the 16 waves of a CU with 12 loads in flight each hide the latency without a prefetch.
+    constexpr bool PREFETCH = NCH < 12;
+    v4i raw[NCH], nxt[PREFETCH ? NCH : 1];
+    if constexpr (PREFETCH) {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int ch = i * 64 + lane;
-        nxt[i] = (v4i){0, 0, 0, 0};
-        if (r < R && ch < nchunks) nxt[i] = *(const v4i *)(x + r * sxr_bytes + (int64_t)ch * 16);
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = i * 64 + lane;
+            nxt[i] = (v4i){0, 0, 0, 0};
+            if (r < R && ch < nchunks) nxt[i] = *(const v4i *)(x + r * sxr_bytes + (int64_t)ch * 16);
+        }
     }
     for (; r < R; r += nwaves) {
+        if constexpr (PREFETCH) {
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) raw[i] = nxt[i];
-        const int64_t rn = r + nwaves;
-        if (rn < R) {
+            for (int i = 0; i < NCH; ++i) raw[i] = nxt[i];
+            const int64_t rn = r + nwaves;
+            if (rn < R) {
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    const int ch = i * 64 + lane;
+                    if (ch < nchunks) nxt[i] = *(const v4i *)(x + rn * sxr_bytes + (int64_t)ch * 16);
+                }
+            }
+        } else {
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 const int ch = i * 64 + lane;
-                if (ch < nchunks) nxt[i] = *(const v4i *)(x + rn * sxr_bytes + (int64_t)ch * 16);
+                raw[i] = (v4i){0, 0, 0, 0};
+                if (ch < nchunks) raw[i] = *(const v4i *)(x + r * sxr_bytes + (int64_t)ch * 16);
             }
         }
         float amax = 0.0f;
