@@ -58,8 +58,9 @@ int gnk_init(void);
  * absmax runs over C for every r (the caller maps `dim` onto this by swapping strides).
  *   scale[r] = amax_c |x[r,c]| / 127            (fp32, true division), stored as x_dtype
  *   q[r,c]   = clip(round_half_even(x[r,c] / max(scale[r], eps)), -128, 127)
- * q has strides (sqr, sqc).  sr != 0 replaces the rounding by floor(v + u), u ~ U[0,1) from
- * Philox4x32-10 keyed by (seed, offset) and indexed by the logical element number r*C + c.
+ * q has strides (sqr, sqc).  sr != 0 replaces the rounding by floor(v + u), u ~ U[0,1): 24 bits of word (e & 3) of the
+ * Philox4x32-10 block with key `seed` and counter e >> 2, e = r*C + c + offset (the logical element number; four
+ * elements share a block).  The reference draws torch.rand_like (int8.py:21): parity under SR is statistical.
  * workspace: device buffer of >= R floats, needed only when the reduction runs along the strided
  * dimension (sxc != 1); may be NULL otherwise.  gnk_quantize_int8_workspace_bytes() tells.
  */
@@ -187,7 +188,7 @@ int gnk_mxfp4_mm(const void *A, const void *B, void *C, int out_dtype, const voi
  * All tensors contiguous, walked flat; eager ATen chains in the reference, one HBM-bound kernel each here.
  *
  * gnk_bitnet_absmean: out[0] = mean(|f32(x)|) as fp32.  Replaces subclasses/bitnet.py:110-112 (get_bitnet_scale).  Fixed
- *   summation order (fp32 per lane, fp64 above): deterministic, within 1e-6 relative of any other order.  workspace: at
+ *   summation order (fp32 within a 16-byte chunk, fp64 above): deterministic, within 1e-6 relative of any other order.  workspace: at
  *   least gnk_bitnet_absmean_workspace_bytes() bytes, 8-byte aligned (per-workgroup partial sums; no need to clear it).
  * gnk_bitnet_quantize_weight: clip(round_half_even(f32(w) / max(scale[0], eps)), -1, 1).  Replaces subclasses/bitnet.py:115-118
  *   (quantize_bitnet_weight); scale is a DEVICE fp32 scalar (no host sync).  packed = 0: out is numel int8 values; packed = 1:

@@ -7,7 +7,7 @@
 //   quantize_bitnet_weight subclasses/bitnet.py:115-118   clip(round(f32(w) / max(scale, eps)), -1, 1) -> int8 (true division, half-even)
 //   _pack_i2_in_i8         subclasses/bitnet.py:185-195   [a, b, c, d] -> (a << 6) | ((b & 3) << 4) | ((c & 3) << 2) | (d & 3)
 //   _unpack_i2_in_i8       subclasses/bitnet.py:198-201   byte -> [x >> 6, x << 2 >> 6, x << 4 >> 6, x << 6 >> 6] (int8 arithmetic: sign extension)
-// The mean is a two-level sum: fp32 per lane (a few hundred terms at most), then fp64 across lanes and workgroups, in a fixed
+// The mean is a two-level sum: fp32 within a 16-byte chunk (4 or 8 terms), fp64 from there on (per lane, across lanes and workgroups), in a fixed
 // order (no atomics: same input -> same bits).  torch's own reduction order differs between devices and versions, so the
 // scale is compared at 1e-6 relative (tests), everything downstream of a GIVEN scale bit-exactly.
 #include "gnk_common.h"
@@ -66,7 +66,7 @@ absmean_partial_kernel(const char *__restrict__ x, double *__restrict__ partials
     __shared__ double lds[BN_THREADS / 64];
     const int64_t nchunks = numel / VEC;
     const int64_t trip = (int64_t)BN_THREADS * BN_UNR;
-    float acc[BN_UNR] = {};
+    double acc[BN_UNR] = {};             // fp32 inside a 16-byte chunk, fp64 from there on: tensors of any size keep 1e-6
     for (int64_t base = (int64_t)blockIdx.x * trip; base < nchunks; base += (int64_t)gridDim.x * trip) {
         v4i raw[BN_UNR];
 #pragma unroll
@@ -81,12 +81,12 @@ absmean_partial_kernel(const char *__restrict__ x, double *__restrict__ partials
             float s = 0.0f;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) s += fabsf(f[j]);
-            acc[u] += s;
+            acc[u] += (double)s;
         }
     }
     double v = 0.0;
 #pragma unroll
-    for (int u = 0; u < BN_UNR; ++u) v += (double)acc[u];
+    for (int u = 0; u < BN_UNR; ++u) v += acc[u];
     if (blockIdx.x == 0 && threadIdx.x == 0)   // the last numel % VEC elements
         for (int64_t i = nchunks * VEC; i < numel; ++i) v += (double)fabsf(gnk_load_scalar<DT>(x, i));
     v = bn_block_sum(v, lds);

@@ -43,7 +43,7 @@ def get_bitnet_scale(x: Tensor) -> Tensor:
 def quantize_bitnet_weight(w: Tensor, scale: Tensor, eps: float = 1e-5) -> Tensor:
     """{-1, 0, +1} as int8: clip(round(w / max(scale, eps)), -1, 1) (reference :115-118)."""
     if w.is_cuda:
-        return _bop.bitnet_quantize_weight(w if w.is_contiguous() else w.contiguous(), scale.float(), eps)
+        return _bop.bitnet_quantize_weight(w if w.is_contiguous() else w.contiguous(), scale.to(device=w.device, dtype=torch.float32), eps)
     return (w.float() / scale.clip(eps)).round().clip(-1, 1).to(torch.int8)
 
 
@@ -64,7 +64,7 @@ def _unpack_i2_in_i8(x: Tensor) -> Tensor:
 def _quantize_and_pack(w: Tensor, scale: Tensor, eps: float = 1e-5) -> Tensor:
     """quantize_bitnet_weight + _pack_i2_in_i8 in one pass over the weight."""
     if w.is_cuda:
-        return _bop.bitnet_quantize_weight(w if w.is_contiguous() else w.contiguous(), scale.float(), eps, packed=True)
+        return _bop.bitnet_quantize_weight(w if w.is_contiguous() else w.contiguous(), scale.to(device=w.device, dtype=torch.float32), eps, packed=True)
     return _pack_i2_in_i8(quantize_bitnet_weight(w, scale, eps))
 
 
