@@ -78,6 +78,26 @@ GNK_DECLARE_LAUNCHER(gnk_launch_f8_11_v1);
         return b_kmajor ? NAME##_l<false, true>(epi, p, st) : NAME##_l<false, false>(epi, p, st);           \
     }
 
+// Tile-scaled GEMM with 64- or 32-k scale blocks (Jetfire-style; QK == 128 stays with the launchers above): the 128 x 128
+// two-buffer kernel with 32-k MFMAs, one instantiation unit per operand class (gnk_gemm_tkb_*.hip).
+#define GNK_DECLARE_TKB(NAME) int NAME(int kb, bool a_kmajor, bool b_kmajor, const GemmParams &p, hipStream_t st)
+GNK_DECLARE_TKB(gnk_launch_tkb_i8);
+GNK_DECLARE_TKB(gnk_launch_tkb_f8_00);
+GNK_DECLARE_TKB(gnk_launch_tkb_f8_01);
+GNK_DECLARE_TKB(gnk_launch_tkb_f8_10);
+GNK_DECLARE_TKB(gnk_launch_tkb_f8_11);
+
+#define GNK_DEFINE_TKB(NAME, OP, FA, FB)                                                                                  \
+    template <int KB> static int NAME##_k(bool ak, bool bk, const GemmParams &p, hipStream_t st) {                        \
+        if (ak) return bk ? gnk_gemm::launch<GemmCfg<128, 128, 2, 2, true, true, OP, FA, FB, EPI_TILE, KB>>(p, st)        \
+                          : gnk_gemm::launch<GemmCfg<128, 128, 2, 2, true, false, OP, FA, FB, EPI_TILE, KB>>(p, st);      \
+        return bk ? gnk_gemm::launch<GemmCfg<128, 128, 2, 2, false, true, OP, FA, FB, EPI_TILE, KB>>(p, st)               \
+                  : gnk_gemm::launch<GemmCfg<128, 128, 2, 2, false, false, OP, FA, FB, EPI_TILE, KB>>(p, st);             \
+    }                                                                                                                     \
+    int NAME(int kb, bool a_kmajor, bool b_kmajor, const GemmParams &p, hipStream_t st) {                                 \
+        return kb == 64 ? NAME##_k<64>(a_kmajor, b_kmajor, p, st) : NAME##_k<32>(a_kmajor, b_kmajor, p, st);              \
+    }
+
 // ---------------------------------------------------------------- generic fallback (gnk_gemm_generic.hip)
 struct GenericParams {
     const char *A;

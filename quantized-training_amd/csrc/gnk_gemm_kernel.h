@@ -37,16 +37,18 @@ struct GemmParams {
     int64_t lda;      // elements between consecutive m (A K-major) or consecutive k (A M-major)
     int64_t ldb;      // elements between consecutive n (B K-major) or consecutive k (B N-major)
     int64_t ssam, ssak, ssbk, ssbn;   // tile-scale strides
-    int64_t QM, QN;                   // tile-scale block sizes along M and N (QK == 128)
+    int64_t QM, QN;                   // tile-scale block sizes along M and N (QK is the kernel's Cfg::KB)
     int out_dtype, scale_dtype, col_scalar, order;
     int grid_m, grid_n;
     int64_t kchunk;   // split-K: k elements per split (gridDim.y splits, each writing its own (M, N) int32 slab at C); 0 = no split
     int debug;        // timing-ablation flags (gnk_set_debug_flags): 1 = no LDS-DMA in the main loop, 2 = no MFMA, 4 = no LDS reads
 };
 
-template <int BM_, int BN_, int WM_, int WN_, bool AK_, bool BK_, int OP_, int FA_, int FB_, int EPI_>
+// KB_: k per scale block of the tile-scaled epilogue (128: one block per K-step; 64 / 32: Jetfire-style blocks, 2 / 4 per step)
+template <int BM_, int BN_, int WM_, int WN_, bool AK_, bool BK_, int OP_, int FA_, int FB_, int EPI_, int KB_ = GNK_BK>
 struct GemmCfg {
-    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, KB = KB_;
+    static_assert(KB_ == 128 || ((KB_ == 64 || KB_ == 32) && EPI_ == 2), "scale blocks of 64 / 32 k exist for the tile-scaled epilogue only");
     static constexpr bool A_KMAJOR = AK_, B_KMAJOR = BK_;
     static constexpr int OP = OP_, FA = FA_, FB = FB_, EPI = EPI_;
     static constexpr int NW = WM * WN, NT = NW * 64;
@@ -186,6 +188,53 @@ __device__ __forceinline__ void compute_step(const char *As, const char *Bs, typ
                                                                              0x7f7f7f7f, 0, 0x7f7f7f7f);   // E8M0 127 = 2^0
         }
     }
+}
+
+// ---- 32-k sub-blocks (tile-scaled with 64 / 32-k scale blocks: the partial sum must stop at a block edge, which the 64-k and
+// 128-k MFMAs cannot).  Lane l = 16 g + r supplies row r and k = 32 s + 8 g .. + 7 of sub-block s (0..3) of the 128-k tile:
+// K-major: half (g & 1) of 16-byte chunk 2 s + (g >> 1); MN-major: one ds_read_b64_tr_b8 over k rows 32 s + 8 g .. + 7.
+template <bool KMAJOR, int ROWS>
+__device__ __forceinline__ long load_frag8(const char *tile, int rb, int s, int lane) {
+    v2i v;
+    if constexpr (KMAJOR) {
+        // == gnk_kmaj_offset(rb + r, 2 s + (g >> 1)) + 8 (g & 1), written so that ONE per-lane term depends on s: rb is a multiple of 16, so
+        // the row's swizzle ((rb + r) >> 1) & 7 is (r >> 1) & 7 for every fragment, and (2 s + gh) ^ sw == (2 s) ^ (gh ^ sw) (gh is bit 0).
+        // Without this the compiler kept one address register per (fragment, sub-block): 32 per operand.
+        const int g = lane >> 4, r = lane & 15;
+        const int u16 = (((g >> 1) ^ (r >> 1)) & 7) << 4;
+        v = *(const GNK_LDS v2i *)(const GNK_LDS char *)(tile + rb * 128 + (r * 128 + 8 * (g & 1)) + ((32 * s) ^ u16));
+    } else {
+        const int g = lane >> 4, q = (lane & 15) >> 1, hb = lane & 1;
+        v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((GNK_LDS v2i *)(tile + gnk_mnmaj_offset<ROWS>(32 * s + 8 * g + q, rb >> 4) + 8 * hb));
+    }
+    return __builtin_bit_cast(long, v);
+}
+
+// one 32-k sub-block of MFMAs for this wave: v_mfma_i32_16x16x32_i8 / v_mfma_f32_16x16x32_{fp8,bf8}_{fp8,bf8}
+template <class Cfg>
+__device__ __forceinline__ void compute_sub32(const char *As, const char *Bs, typename AccT<Cfg::OP>::type (&acc)[Cfg::MT][Cfg::NTL],
+                                              int wm, int wn, int lane, int s, bool fresh) {
+    constexpr int MT = Cfg::MT, NTL = Cfg::NTL;
+    long fa[MT], fb[NTL];
+    asm volatile("" ::: "memory");   // compiler-only fence: without it the fragment reads of all sub-blocks were hoisted to the top (spills)
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) fb[j] = load_frag8<Cfg::B_KMAJOR, Cfg::BN>(Bs, wn * Cfg::WTN + 16 * j, s, lane);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) fa[i] = load_frag8<Cfg::A_KMAJOR, Cfg::BM>(As, wm * Cfg::WTM + 16 * i, s, lane);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            if constexpr (Cfg::OP == OP_I8) {
+                acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x32_i8(fb[j], fa[i], fresh ? (v4i){0, 0, 0, 0} : acc[i][j], 0, 0, 0);
+            } else {   // the first MFMA operand is the B fragment: its format is FB (0 = e4m3 "fp8", 1 = e5m2 "bf8")
+                const v4f c = fresh ? (v4f){0.f, 0.f, 0.f, 0.f} : acc[i][j];
+                if constexpr (Cfg::FB == 0 && Cfg::FA == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(fb[j], fa[i], c, 0, 0, 0);
+                else if constexpr (Cfg::FB == 0 && Cfg::FA == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(fb[j], fa[i], c, 0, 0, 0);
+                else if constexpr (Cfg::FB == 1 && Cfg::FA == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf8_fp8(fb[j], fa[i], c, 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(fb[j], fa[i], c, 0, 0, 0);
+            }
+        }
 }
 
 // ------------------------------------------------------------------------------ epilogue stores
@@ -566,17 +615,32 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
     // A side: per-lane fetches of sA[m / QM, t] touch 16 rows per load instruction (row-major sA: 16 cache lines for 32 bytes)
     // and cost 15-25 % of the kernel; instead the workgroup stages a PANEL of its BM rows x 8 K-blocks in LDS (fp32, [step][row])
     // with one element per thread and load, k fastest (coalesced for row-major sA), once per 8 steps.
+    // Scale blocks of Cfg::KB k: NB per 128-k step.  "Scale step" u = t * NB + b indexes sA[:, u] / sB[u, :]; the panel holds 8 of them.
     constexpr int TS_STEPS = 8, TS_PE = Cfg::EPI == EPI_TILE ? Cfg::BM * TS_STEPS / Cfg::NT : 1;
+    constexpr int NB = GNK_BK / Cfg::KB, PS = TS_STEPS / NB;    // PS: K-steps per panel
+    // NB > 1: the B-side scales go through a second panel ([scale step][BN columns]) too -- NB x NTL per-lane values for this step
+    // and as many in flight for the next one spilled registers.
+    constexpr bool PANEL_B = NB > 1;
+    constexpr int TS_PEB = PANEL_B ? Cfg::BN * TS_STEPS / Cfg::NT : 1;
     const int nk = (int)(p.K / GNK_BK);
+    const int nks = nk * NB;
     TileScaleIdx<Cfg> ts;
-    unsigned raw_b[Cfg::EPI == EPI_TILE ? NTL : 1], praw[TS_PE];
-    int poff[TS_PE];
+    unsigned raw_b[Cfg::EPI == EPI_TILE && !PANEL_B ? NTL : 1], praw[TS_PE], prawb[TS_PEB];
+    int poff[TS_PE], poffb[TS_PEB];
     float *const panel = (float *)(smem + Cfg::LDS_BYTES);
+    float *const panel_b = panel + Cfg::BM * TS_STEPS;
     auto panel_fetch = [&](int pn) {
 #pragma unroll
         for (int u = 0; u < TS_PE; ++u) {
             const int tt = pn * TS_STEPS + (((int)threadIdx.x + Cfg::NT * u) % TS_STEPS);
-            praw[u] = tt < nk ? gnk_load_raw_rt(p.s0, p.scale_dtype, poff[u] + tt * (int)p.ssak) : 0u;
+            praw[u] = tt < nks ? gnk_load_raw_rt(p.s0, p.scale_dtype, poff[u] + tt * (int)p.ssak) : 0u;
+        }
+        if constexpr (PANEL_B) {
+#pragma unroll
+            for (int u = 0; u < TS_PEB; ++u) {
+                const int tt = pn * TS_STEPS + (((int)threadIdx.x + Cfg::NT * u) % TS_STEPS);
+                prawb[u] = tt < nks ? gnk_load_raw_rt(p.s1, p.scale_dtype, poffb[u] + tt * (int)p.ssbk) : 0u;
+            }
         }
     };
     auto panel_store = [&]() {
@@ -584,6 +648,13 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
         for (int u = 0; u < TS_PE; ++u) {
             const int e = (int)threadIdx.x + Cfg::NT * u;
             *(GNK_LDS float *)(GNK_LDS char *)((char *)panel + ((e % TS_STEPS) * Cfg::BM + e / TS_STEPS) * 4) = gnk_raw_to_f32_rt(praw[u], p.scale_dtype);
+        }
+        if constexpr (PANEL_B) {
+#pragma unroll
+            for (int u = 0; u < TS_PEB; ++u) {
+                const int e = (int)threadIdx.x + Cfg::NT * u;
+                *(GNK_LDS float *)(GNK_LDS char *)((char *)panel_b + ((e % TS_STEPS) * Cfg::BN + e / TS_STEPS) * 4) = gnk_raw_to_f32_rt(prawb[u], p.scale_dtype);
+            }
         }
     };
     if constexpr (Cfg::EPI == EPI_TILE) {
@@ -594,8 +665,16 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
             m = m < p.M ? m : p.M - 1;
             poff[u] = (int)(((unsigned)m / (unsigned)p.QM) * (unsigned)p.ssam);
         }
+        if constexpr (PANEL_B) {
+#pragma unroll
+            for (int u = 0; u < TS_PEB; ++u) {
+                int64_t n = n0 + ((int)threadIdx.x + Cfg::NT * u) / TS_STEPS;
+                n = n < p.N ? n : p.N - 1;
+                poffb[u] = (int)(((unsigned)n / (unsigned)p.QN) * (unsigned)p.ssbn);
+            }
+        }
         if (nk > 0) {
-            ts.load_raw_b(p, 0, raw_b);
+            if constexpr (!PANEL_B) ts.load_raw_b(p, 0, raw_b);
             panel_fetch(0);
         }
     }
@@ -610,20 +689,19 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
 
         // tile-scaled: this K-block's scales arrived with the vmcnt(0) above; fetch the next block's BEFORE
         // the next stage is issued (they are waited for together at the top of the next step)
-        float sav[Cfg::EPI == EPI_TILE ? MT : 1];
-        float sbv[Cfg::EPI == EPI_TILE ? NTL : 1];
+        float sbv1[Cfg::EPI == EPI_TILE && !PANEL_B ? NTL : 1];
+        int tsi = 0;
         if constexpr (Cfg::EPI == EPI_TILE) {
-            const int tsi = t % TS_STEPS;
-            if (tsi == 0) {            // the panel of steps t .. t + 7 was fetched during step t - 1 (or before the loop)
+            tsi = t % PS;
+            if (tsi == 0) {            // the panel of scale steps t * NB .. + 7 was fetched during the step before it (or before the loop)
                 panel_store();
                 __syncthreads();
             }
-            TileScaleIdx<Cfg>::convert_b(p, raw_b, sbv);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-                sav[i] = *(const GNK_LDS float *)(const GNK_LDS char *)((const char *)panel + (tsi * Cfg::BM + wm * Cfg::WTM + 16 * i + (lane & 15)) * 4);
-            if (t + 1 < nk) ts.load_raw_b(p, t + 1, raw_b);
-            if (tsi == TS_STEPS - 1 && t + 1 < nk) panel_fetch((t + 1) / TS_STEPS);
+            if constexpr (!PANEL_B) {
+                TileScaleIdx<Cfg>::convert_b(p, raw_b, sbv1);
+                if (t + 1 < nk) ts.load_raw_b(p, t + 1, raw_b);
+            }
+            if (tsi == PS - 1 && t + 1 < nk) panel_fetch((t + 1) / PS);
         }
 
         const int cur = t & 1;
@@ -631,24 +709,47 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
             sa.issue(As0 + (cur ^ 1) * Cfg::A_BYTES, wave);
             sb.issue(Bs0 + (cur ^ 1) * Cfg::B_BYTES, wave);
         }
-        compute_step<Cfg, Cfg::EPI == EPI_TILE>(As0 + cur * Cfg::A_BYTES, Bs0 + cur * Cfg::B_BYTES, acc, wm, wn, lane);
-
-        if constexpr (Cfg::EPI == EPI_TILE) {
-            // acc_f32 += (f32(partial) * sA[m/QM, t]) * sB[t, n/QN]   (triton_mm.py:327-331), no FMA
+        if constexpr (Cfg::EPI != EPI_TILE) {
+            compute_step<Cfg, false>(As0 + cur * Cfg::A_BYTES, Bs0 + cur * Cfg::B_BYTES, acc, wm, wn, lane);
+        } else {
+            // NB > 1: a REAL loop over the step's blocks.  Every block starts from C = 0, so nothing orders block b + 1's MFMAs after
+            // block b's rescale; unrolled, the scheduler issued all four blocks' MFMAs first (four accumulator sets live: 160 spills).
+#pragma unroll 1
+            for (int b = 0; b < NB; ++b) {
+                if constexpr (NB == 1) {
+                    compute_step<Cfg, true>(As0 + cur * Cfg::A_BYTES, Bs0 + cur * Cfg::B_BYTES, acc, wm, wn, lane);
+                } else {
 #pragma unroll
-            for (int j = 0; j < NTL; ++j)
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float part;
-                        if constexpr (Cfg::OP == OP_I8) part = (float)acc[i][j][r];
-                        else part = acc[i][j][r];
-                        float tmp = __fmul_rn(part, sav[i]);
-                        tmp = __fmul_rn(tmp, sbv[j]);
-                        accf[i][j][r] = __fadd_rn(accf[i][j][r], tmp);
-                    }
+                    for (int s2 = 0; s2 < Cfg::KB / 32; ++s2)
+                        compute_sub32<Cfg>(As0 + cur * Cfg::A_BYTES, Bs0 + cur * Cfg::B_BYTES, acc, wm, wn, lane, b * (Cfg::KB / 32) + s2, s2 == 0);
                 }
+                // this block's scales from the panel(s) (fp32, [scale step][row] / [scale step][column])
+                float sav[MT], sbv[NTL];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    sav[i] = *(const GNK_LDS float *)(const GNK_LDS char *)((const char *)panel + ((tsi * NB + b) * Cfg::BM + wm * Cfg::WTM + 16 * i + (lane & 15)) * 4);
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) {
+                    if constexpr (PANEL_B)
+                        sbv[j] = *(const GNK_LDS float *)(const GNK_LDS char *)((const char *)panel_b + ((tsi * NB + b) * Cfg::BN + wn * Cfg::WTN + 16 * j + 4 * (lane >> 4)) * 4);
+                    else sbv[j] = sbv1[j];
+                }
+                // acc_f32 += (f32(partial) * sA[m/QM, u]) * sB[u, n/QN]   (triton_mm.py:327-331), no FMA
+#pragma unroll
+                for (int j = 0; j < NTL; ++j)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float part;
+                            if constexpr (Cfg::OP == OP_I8) part = (float)acc[i][j][r];
+                            else part = acc[i][j][r];
+                            float tmp = __fmul_rn(part, sav[i]);
+                            tmp = __fmul_rn(tmp, sbv[j]);
+                            accf[i][j][r] = __fadd_rn(accf[i][j][r], tmp);
+                        }
+                    }
+            }
         }
     }
 
@@ -660,7 +761,8 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
 }
 
 template <class Cfg> int launch(const GemmParams &p0, hipStream_t st) {
-    constexpr int LDS_TOTAL = Cfg::LDS_BYTES + ScalePrefetch<Cfg::BM, Cfg::BN, Cfg::NT, Cfg::EPI>::BYTES + (Cfg::EPI == EPI_TILE ? Cfg::BM * 8 * 4 : 0);
+    constexpr int LDS_TOTAL = Cfg::LDS_BYTES + ScalePrefetch<Cfg::BM, Cfg::BN, Cfg::NT, Cfg::EPI>::BYTES + (Cfg::EPI == EPI_TILE ? Cfg::BM * 8 * 4 : 0) +
+                              (Cfg::EPI == EPI_TILE && Cfg::KB != GNK_BK ? Cfg::BN * 8 * 4 : 0);   // tile-scaled: A-side scale panel (+ B-side panel for 64 / 32-k blocks)
     GemmParams p = p0;
     p.grid_m = (int)((p.M + Cfg::BM - 1) / Cfg::BM);
     p.grid_n = (int)((p.N + Cfg::BN - 1) / Cfg::BN);

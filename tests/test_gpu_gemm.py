@@ -157,6 +157,42 @@ def test_tile_scaled_int8_vs_oracle(blocks):
     assert bits_equal(got, oracle.scaled_mm(A, B, sA, sB))
 
 
+@pytest.mark.parametrize("blocks", [(32, 32, 32), (64, 64, 64), (1, 128, 32), (32, 4, 64)])
+@pytest.mark.parametrize("layout", list(LAYOUTS))
+def test_tile_scaled_small_k_blocks_int8_bit_exact(blocks, layout):
+    """Jetfire-style blocks (BASELINE configs[2]): 64- and 32-k scale blocks on the 32-k MFMA instances -- every operand layout,
+    bf16 and fp32 scales, K longer than one scale panel (8 scale steps), ragged M / N edges."""
+    QM, QN, QK = blocks
+    M, N, K = 384 + QM * 2, 512 + QN * 3 if QN >= 4 else 512, 1280
+    M, N = (M // QM) * QM, (N // QN) * QN
+    g = torch.Generator().manual_seed(QM * 7 + QN + QK)
+    acm, bcm = LAYOUTS[layout]
+    A = to_layout(torch.randint(-128, 128, (M, K), dtype=torch.int8, generator=g), acm)
+    B = to_layout(torch.randint(-128, 128, (K, N), dtype=torch.int8, generator=g), bcm)
+    sA = torch.randn(M // QM, K // QK, generator=g).div(128)
+    sB = torch.randn(K // QK, N // QN, generator=g).div(128)
+    Ad, Bd = dev_layout(A, acm), dev_layout(B, bcm)
+    assert bits_equal(gn_kernels.scaled_mm(Ad, Bd, sA.to(DEV), sB.to(DEV)), oracle.scaled_mm(A, B, sA, sB))
+    sAh, sBh = sA.bfloat16(), sB.bfloat16()
+    assert bits_equal(gn_kernels.scaled_mm(Ad, Bd, sAh.to(DEV), sBh.to(DEV)), oracle.scaled_mm(A, B, sAh, sBh))
+    sAt = sA.T.contiguous().T                                                    # column-major sA, as benchmark_mm.py:91-96 lays it out
+    assert bits_equal(gn_kernels.scaled_mm(Ad, Bd, sAt.to(DEV).T.contiguous().T, sB.to(DEV)), oracle.scaled_mm(A, B, sA, sB))
+
+
+@pytest.mark.parametrize("fmts", [("e4m3", "e4m3"), ("e5m2", "e4m3"), ("e4m3", "e5m2"), ("e5m2", "e5m2")])
+@pytest.mark.parametrize("qk", [32, 64])
+def test_tile_scaled_small_k_blocks_fp8(fmts, qk):
+    M, N, K = 256, 384, 640
+    g = torch.Generator().manual_seed(qk + len(fmts[0]))
+    for layout, (acm, bcm) in LAYOUTS.items():
+        A = to_layout(torch.randn(M, K, generator=g).to(FP8_DTYPES[fmts[0]]), acm)
+        B = to_layout(torch.randn(K, N, generator=g).to(FP8_DTYPES[fmts[1]]), bcm)
+        sA = torch.randn(M // 32, K // qk, generator=g).div(128)
+        sB = torch.randn(K // qk, N // 32, generator=g).div(128)
+        got = gn_kernels.scaled_mm(dev_layout(A, acm), dev_layout(B, bcm), sA.to(DEV), sB.to(DEV))
+        assert_fp8_close(got, oracle.scaled_mm(A, B, sA, sB), fp8_mag(A, B, sA, sB))
+
+
 @pytest.mark.parametrize("fmts", [("e4m3", "e4m3"), ("e5m2", "e4m3"), ("e4m3", "e5m2"), ("e5m2", "e5m2")])
 @pytest.mark.parametrize("layout", list(LAYOUTS))
 def test_fp8_paths_vs_oracle(fmts, layout, variant):
