@@ -60,6 +60,12 @@ def make_inputs(S, dev):
         cases[("fp8", name)] = (to_layout(A_f8, acm), to_layout(B_f8, bcm), sA, sB)
         cases[("tile_int8", name)] = (to_layout(A_i8, acm), to_layout(B_i8, bcm), to_layout(tsA, acm), to_layout(tsB, bcm))
         cases[("tile_fp8", name)] = (to_layout(A_f8, acm), to_layout(B_f8, bcm), to_layout(tsA, acm), to_layout(tsB, bcm))
+    if S >= 4096:   # BASELINE configs[2]: Jetfire-style 32 x 32 x 32 blocks (the same op with (M/32, K/32) / (K/32, N/32) scales)
+        jsA = torch.randn(S // 32, S // 32, device=dev).div(128).bfloat16()
+        jsB = torch.randn(S // 32, S // 32, device=dev).div(128).bfloat16()
+        for name, (acm, bcm) in LAYOUTS.items():
+            cases[("tile_int8_jetfire32", name)] = (to_layout(A_i8, acm), to_layout(B_i8, bcm), jsA, jsB)
+            cases[("tile_fp8_jetfire32", name)] = (to_layout(A_f8, acm), to_layout(B_f8, bcm), jsA, jsB)
     return cases
 
 

@@ -347,3 +347,27 @@ def test_full_size_4096_tile_scaled_and_fp8():
     out8 = gn_kernels.scaled_mm(A8, B8, rs, cs)
     want8 = (A8[:128].float() * rs[:128].float()) @ (B8.float() * cs.float())                   # scaled_mm_ref, benchmark_mm.py:46-50
     assert_fp8_close(out8[:128], want8, fp8_mag(A8[:128], B8, rs[:128], cs))
+
+
+@pytest.mark.parametrize("layout", list(LAYOUTS))
+def test_full_size_4096_jetfire_blocks(layout):
+    """BASELINE configs[2] at its full size: 32 x 32 x 32 scale blocks.  Row blocks of the output depend on the same rows of A
+    and of sA only, so four 32-row blocks spread over the matrix are checked bit-for-bit against the oracle over all of N and K;
+    linearity in the scales (doubling sA doubles every fp32 output exactly) covers the rest."""
+    torch.manual_seed(2025 * 2024 + 1)
+    S, Q = 4096, 32
+    acm, bcm = LAYOUTS[layout]
+    A = to_layout(torch.randint(-128, 127, (S, S), dtype=torch.int8, device=DEV), acm)
+    B = to_layout(torch.randint(-128, 127, (S, S), dtype=torch.int8, device=DEV), bcm)
+    sA = torch.randn(S // Q, S // Q, device=DEV).div(128)
+    sB = torch.randn(S // Q, S // Q, device=DEV).div(128)
+    out = gn_kernels.scaled_mm(A, B, sA, sB)
+    assert out.dtype is torch.float32 and out.shape == (S, S)
+    Bc = B.cpu()
+    for blk in (0, 41, 86, 127):
+        r = slice(blk * Q, (blk + 1) * Q)
+        want = oracle.scaled_mm(A[r].cpu().contiguous(), Bc, sA[blk:blk + 1].cpu().contiguous(), sB.cpu())
+        assert bits_equal(out[r], want)
+    assert torch.equal(gn_kernels.scaled_mm(A, B, sA * 2, sB), out * 2)        # power-of-two scaling commutes with every rounding
+    outh = gn_kernels.scaled_mm(A, B, sA.bfloat16(), sB.bfloat16())
+    assert outh.dtype is torch.bfloat16 and torch.isfinite(outh.float()).all()
