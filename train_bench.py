@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--weight_decay", type=float, default=1e-2)
     ap.add_argument("--activation_checkpointing", action="store_true")
     ap.add_argument("--device", default="cuda")
+    ap.add_argument("--data", default="uniform", choices=["uniform", "markov"], help="uniform random tokens (throughput runs) or a learnable Markov stream (loss-curve runs)")
+    ap.add_argument("--log_losses", action="store_true", help="record the loss of every step (adds one host sync per step: not for throughput numbers)")
     ap.add_argument("--no_quantize_cache", action="store_true", help="A/B: re-quantize a tensor every time it is used (subclasses.mixed_precision.set_quantize_plan)")
     ap.add_argument("--no_fused_quantize", action="store_true", help="A/B: never use the fused row-wise + column-absmax kernels")
     ap.add_argument("--gnk_debug_flags", type=int, default=0, help="A/B timing switches of libgnk_hip.so (gnk_set_debug_flags)")
@@ -115,8 +117,20 @@ def main():
         model = DDP(model, device_ids=[local_rank] if on_gpu else None)
     optim = torch.optim.AdamW(model.parameters(), lr=args.lr, weight_decay=args.weight_decay, fused=on_gpu and args.quantize != "int8")
 
+    # --data markov: a LEARNABLE synthetic stream (next token = perm[token] with probability 0.9, else uniform), so that loss curves of
+    # the quantized and bf16 runs can be compared while the loss actually falls; uniform random tokens only ever reach log(32000).
+    data_gen = torch.Generator(device=dev).manual_seed(4321 + rank)
+    perm = torch.randperm(32000, generator=torch.Generator().manual_seed(99)).to(dev)
+
     def batch():
-        t = torch.randint(0, 32000, (bsize, args.seq_len + 1), device=dev)
+        if args.data == "uniform":
+            t = torch.randint(0, 32000, (bsize, args.seq_len + 1), device=dev)
+        else:
+            noise = torch.randint(0, 32000, (bsize, args.seq_len + 1), device=dev, generator=data_gen)
+            keep = torch.rand((bsize, args.seq_len + 1), device=dev, generator=data_gen) < 0.9
+            t = noise.clone()
+            for i in range(1, args.seq_len + 1):                       # short python loop over positions (data only, outside the model)
+                t[:, i] = torch.where(keep[:, i], perm[t[:, i - 1]], noise[:, i])
         return t[:, :-1].contiguous(), t[:, 1:].contiguous()
 
     def step():
@@ -138,8 +152,11 @@ def main():
         losses.append(step().item())
     sync()
     t0 = time.perf_counter()
+    curve = []
     for _ in range(args.steps):
         last = step()
+        if args.log_losses:
+            curve.append(round(last.item(), 4))
     sync()
     dt = time.perf_counter() - t0
     losses.append(last.item())
@@ -161,6 +178,7 @@ def main():
                        "params": n_params, "body_linear_weights": lin},
             "body_linear_TOPS": round(6 * args.batch_size * args.seq_len * lin * args.steps / dt * 1e-12, 1),
             "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)],
+            **({"loss_curve": curve, "data": f"synthetic {args.data} tokens, random-init weights"} if args.log_losses else {}),
         }
         if on_gpu:
             out["max_mem_GiB"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
