@@ -177,3 +177,32 @@ def test_train_bench_int8_mixed_precision_step_runs_on_the_gpu():
         assert out["value"] > 0
         losses[q] = out["loss_first_last"]
     assert abs(losses["none"][0] - losses["mixed_precision"][0]) < 0.02 and abs(losses["none"][1] - losses["mixed_precision"][1]) < 0.05
+
+
+def test_loss_curve_matches_the_cpu_restatement_over_50_steps(oracle_cpu_ops):
+    """SURVEY 9.9's loss criterion: 50 AdamW steps of an INT8 mixed-precision MLP on the device (HIP kernels) and on the host
+    (the CPU oracle registered as the ops' CPU backend), identical seeds and data.  STATED TOLERANCE: |loss_gpu - loss_cpu| <= 1e-2
+    at every step (the GEMMs are bit-identical; what differs is bf16 GELU / AdamW arithmetic between the two devices)."""
+
+    def run(dev):
+        torch.manual_seed(0)
+        model = nn.Sequential(nn.Linear(128, 256), nn.GELU(), nn.Linear(256, 256), nn.GELU(), nn.Linear(256, 64)).to(BF).to(dev)
+        convert_mixed_precision(model)
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+        g = torch.Generator().manual_seed(1)
+        teacher = torch.randn(128, 64, generator=g) / 8
+        losses = []
+        for _ in range(50):
+            x = torch.randn(256, 128, generator=g).to(BF)
+            y = (x.float() @ teacher).tanh().to(BF)
+            loss = (model(x.to(dev)).float() - y.to(dev).float()).square().mean()
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            losses.append(loss.item())
+        return losses
+
+    cpu, gpu = run("cpu"), run(DEV)
+    assert cpu[-1] < 0.6 * cpu[0], cpu                                   # it learns
+    worst = max(abs(a - b) for a, b in zip(cpu, gpu))
+    assert worst <= 1e-2, (worst, cpu[::10], gpu[::10])
