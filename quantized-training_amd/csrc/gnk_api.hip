@@ -205,11 +205,11 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
                              lb.ld * 256 < (1LL << 31) && ((c.M + 127) / 128) * ((c.N + 127) / 128) < (1LL << 31);
     // 4-stage 256^2 kernel: 64-k stages, no tile-scaled epilogue; the two-buffer kernels step 128 k
     const bool ok_pp2 = fast_layout && c.K >= 64 && c.K % 64 == 0 && c.epi != EPI_TILE;
-    // tile-scaled fast path: scale blocks of 128, 64 or 32 k (1, 2 or 4 per 128-k step), and scale offsets that fit 32-bit indices
+    // tile-scaled fast path: scale blocks of 64 or 32 k (2 or 4 per 128-k step) or of a multiple of 128 k, and scale offsets that fit 32-bit indices
     bool tile_ok = true;
     if (c.epi == EPI_TILE) {
         const int64_t amax = ((c.M - 1) / c.QM) * c.ssam + (c.K / c.QK) * c.ssak, bmax = (c.K / c.QK) * c.ssbk + ((c.N - 1) / c.QN) * c.ssbn;
-        tile_ok = (c.QK == GNK_BK || c.QK == 64 || c.QK == 32) && c.QN % 4 == 0 && c.N % 4 == 0 && c.ssam >= 0 && c.ssak >= 0 && c.ssbk >= 0 && c.ssbn >= 0 && amax < (1LL << 31) && bmax < (1LL << 31);
+        tile_ok = (c.QK % GNK_BK == 0 || c.QK == 64 || c.QK == 32) && c.QK / GNK_BK < (1 << 20) && c.K % c.QK == 0 && c.QN % 4 == 0 && c.N % 4 == 0 && c.ssam >= 0 && c.ssak >= 0 && c.ssbk >= 0 && c.ssbn >= 0 && amax < (1LL << 31) && bmax < (1LL << 31);
     }
     const bool ok_128 = fast_layout && c.K >= GNK_BK && c.K % GNK_BK == 0 && tile_ok;
     if ((variant == GNK_VARIANT_256_SIMPLE || variant == GNK_VARIANT_256_PP8) && (op != OP_I8 || c.epi == EPI_TILE)) variant = GNK_VARIANT_256;
@@ -264,7 +264,8 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
     p.ssam = c.ssam; p.ssak = c.ssak; p.ssbk = c.ssbk; p.ssbn = c.ssbn; p.QM = c.QM; p.QN = c.QN;
     p.out_dtype = c.out_dtype; p.scale_dtype = c.scale_dtype; p.col_scalar = c.col_scalar; p.order = c.order;
     p.debug = g_debug_flags;
-    if (c.epi == EPI_TILE && c.QK != GNK_BK) {   // Jetfire-style blocks: the 32-k MFMA instances of the 128 x 128 kernel
+    p.kgroup = c.epi == EPI_TILE && c.QK > GNK_BK ? (int)(c.QK / GNK_BK) : 1;
+    if (c.epi == EPI_TILE && c.QK < GNK_BK) {   // Jetfire-style blocks: the 32-k MFMA instances of the 128 x 128 kernel
         if (op == OP_I8) return gnk_launch_tkb_i8((int)c.QK, la.kmajor, lb.kmajor, p, st);
         if (fa == F8_E4M3) return fb == F8_E4M3 ? gnk_launch_tkb_f8_00((int)c.QK, la.kmajor, lb.kmajor, p, st) : gnk_launch_tkb_f8_01((int)c.QK, la.kmajor, lb.kmajor, p, st);
         return fb == F8_E4M3 ? gnk_launch_tkb_f8_10((int)c.QK, la.kmajor, lb.kmajor, p, st) : gnk_launch_tkb_f8_11((int)c.QK, la.kmajor, lb.kmajor, p, st);

@@ -40,6 +40,7 @@ struct GemmParams {
     int64_t QM, QN;                   // tile-scale block sizes along M and N (QK is the kernel's Cfg::KB)
     int out_dtype, scale_dtype, col_scalar, order;
     int grid_m, grid_n;
+    int kgroup;       // tile-scaled with QK = kgroup * 128 (kgroup >= 1; 1 for the 64 / 32-k block kernels): K-steps per scale block
     int64_t kchunk;   // split-K: k elements per split (gridDim.y splits, each writing its own (M, N) int32 slab at C); 0 = no split
     int debug;        // timing-ablation flags (gnk_set_debug_flags): 1 = no LDS-DMA in the main loop, 2 = no MFMA, 4 = no LDS reads
 };
@@ -623,7 +624,9 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
     constexpr bool PANEL_B = NB > 1;
     constexpr int TS_PEB = PANEL_B ? Cfg::BN * TS_STEPS / Cfg::NT : 1;
     const int nk = (int)(p.K / GNK_BK);
-    const int nks = nk * NB;
+    const int G = Cfg::EPI == EPI_TILE && NB == 1 && p.kgroup > 1 ? p.kgroup : 1;   // K-steps per scale block (QK = G * 128)
+    const int nks = (nk * NB + G - 1) / G;                                          // scale steps along K
+    const int psteps = PS * G;                                                      // K-steps covered by one panel
     TileScaleIdx<Cfg> ts;
     unsigned raw_b[Cfg::EPI == EPI_TILE && !PANEL_B ? NTL : 1], praw[TS_PE], prawb[TS_PEB];
     int poff[TS_PE], poffb[TS_PEB];
@@ -692,16 +695,17 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
         float sbv1[Cfg::EPI == EPI_TILE && !PANEL_B ? NTL : 1];
         int tsi = 0;
         if constexpr (Cfg::EPI == EPI_TILE) {
-            tsi = t % PS;
-            if (tsi == 0) {            // the panel of scale steps t * NB .. + 7 was fetched during the step before it (or before the loop)
+            const int tk = t % psteps;
+            tsi = tk / G;              // scale step of this K-step within the panel (times NB)
+            if (tk == 0) {             // the panel of the next 8 scale steps was fetched during the step before it (or before the loop)
                 panel_store();
                 __syncthreads();
             }
             if constexpr (!PANEL_B) {
                 TileScaleIdx<Cfg>::convert_b(p, raw_b, sbv1);
-                if (t + 1 < nk) ts.load_raw_b(p, t + 1, raw_b);
+                if (t + 1 < nk) ts.load_raw_b(p, (t + 1) / G, raw_b);
             }
-            if (tsi == PS - 1 && t + 1 < nk) panel_fetch((t + 1) / PS);
+            if (tk == psteps - 1 && t + 1 < nk) panel_fetch((t + 1) / psteps);
         }
 
         const int cur = t & 1;
@@ -717,7 +721,10 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
 #pragma unroll 1
             for (int b = 0; b < NB; ++b) {
                 if constexpr (NB == 1) {
-                    compute_step<Cfg, true>(As0 + cur * Cfg::A_BYTES, Bs0 + cur * Cfg::B_BYTES, acc, wm, wn, lane);
+                    // QK = G * 128: the partial sum runs over G steps (exact in int32) and is rescaled after the last of them
+                    if (G == 1 || t % G == 0) compute_step<Cfg, true>(As0 + cur * Cfg::A_BYTES, Bs0 + cur * Cfg::B_BYTES, acc, wm, wn, lane);
+                    else compute_step<Cfg, false>(As0 + cur * Cfg::A_BYTES, Bs0 + cur * Cfg::B_BYTES, acc, wm, wn, lane);
+                    if (G > 1 && (t + 1) % G != 0) continue;
                 } else {
 #pragma unroll
                     for (int s2 = 0; s2 < Cfg::KB / 32; ++s2)

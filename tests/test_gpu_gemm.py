@@ -157,11 +157,12 @@ def test_tile_scaled_int8_vs_oracle(blocks):
     assert bits_equal(got, oracle.scaled_mm(A, B, sA, sB))
 
 
-@pytest.mark.parametrize("blocks", [(32, 32, 32), (64, 64, 64), (1, 128, 32), (32, 4, 64)])
+@pytest.mark.parametrize("blocks", [(32, 32, 32), (64, 64, 64), (1, 128, 32), (32, 4, 64), (128, 128, 256), (1, 64, 640), (32, 32, 1280)])
 @pytest.mark.parametrize("layout", list(LAYOUTS))
 def test_tile_scaled_small_k_blocks_int8_bit_exact(blocks, layout):
-    """Jetfire-style blocks (BASELINE configs[2]): 64- and 32-k scale blocks on the 32-k MFMA instances -- every operand layout,
-    bf16 and fp32 scales, K longer than one scale panel (8 scale steps), ragged M / N edges."""
+    """Jetfire-style blocks (BASELINE configs[2]): 64- and 32-k scale blocks on the 32-k MFMA instances, and blocks of a multiple of
+    128 k (partial sums carried over several K-steps) -- every operand layout, bf16 and fp32 scales, K longer than one scale panel
+    (8 scale steps), ragged M / N edges."""
     QM, QN, QK = blocks
     M, N, K = 384 + QM * 2, 512 + QN * 3 if QN >= 4 else 512, 1280
     M, N = (M // QM) * QM, (N // QN) * QN
