@@ -265,7 +265,7 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
     p.out_dtype = c.out_dtype; p.scale_dtype = c.scale_dtype; p.col_scalar = c.col_scalar; p.order = c.order;
     p.debug = g_debug_flags;
     p.kgroup = c.epi == EPI_TILE && c.QK > GNK_BK ? (int)(c.QK / GNK_BK) : 1;
-    if (c.epi == EPI_TILE && c.QK < GNK_BK) {   // Jetfire-style blocks: the 32-k MFMA instances of the 128 x 128 kernel
+    if (c.epi == EPI_TILE && c.QK != GNK_BK) {   // Jetfire-style blocks / blocks of several K-steps: the 32-k MFMA instances of the 128 x 128 kernel
         if (op == OP_I8) return gnk_launch_tkb_i8((int)c.QK, la.kmajor, lb.kmajor, p, st);
         if (fa == F8_E4M3) return fb == F8_E4M3 ? gnk_launch_tkb_f8_00((int)c.QK, la.kmajor, lb.kmajor, p, st) : gnk_launch_tkb_f8_01((int)c.QK, la.kmajor, lb.kmajor, p, st);
         return fb == F8_E4M3 ? gnk_launch_tkb_f8_10((int)c.QK, la.kmajor, lb.kmajor, p, st) : gnk_launch_tkb_f8_11((int)c.QK, la.kmajor, lb.kmajor, p, st);

@@ -78,8 +78,9 @@ GNK_DECLARE_LAUNCHER(gnk_launch_f8_11_v1);
         return b_kmajor ? NAME##_l<false, true>(epi, p, st) : NAME##_l<false, false>(epi, p, st);           \
     }
 
-// Tile-scaled GEMM with 64- or 32-k scale blocks (Jetfire-style; QK == 128 stays with the launchers above): the 128 x 128
-// two-buffer kernel with 32-k MFMAs, one instantiation unit per operand class (gnk_gemm_tkb_*.hip).
+// Tile-scaled GEMM with 64- or 32-k scale blocks (Jetfire-style: 32-k MFMAs) or blocks of a multiple of 128 k above 128 (QK == 128
+// stays with the launchers above): instances of the 128 x 128 two-buffer kernel, one instantiation unit per operand class
+// (gnk_gemm_tkb_*.hip).
 #define GNK_DECLARE_TKB(NAME) int NAME(int kb, bool a_kmajor, bool b_kmajor, const GemmParams &p, hipStream_t st)
 GNK_DECLARE_TKB(gnk_launch_tkb_i8);
 GNK_DECLARE_TKB(gnk_launch_tkb_f8_00);
@@ -95,6 +96,7 @@ GNK_DECLARE_TKB(gnk_launch_tkb_f8_11);
                   : gnk_gemm::launch<GemmCfg<128, 128, 2, 2, false, false, OP, FA, FB, EPI_TILE, KB>>(p, st);             \
     }                                                                                                                     \
     int NAME(int kb, bool a_kmajor, bool b_kmajor, const GemmParams &p, hipStream_t st) {                                 \
+        if (kb > 128) return NAME##_k<256>(a_kmajor, b_kmajor, p, st);   /* any multiple of 128: p.kgroup steps per block */  \
         return kb == 64 ? NAME##_k<64>(a_kmajor, b_kmajor, p, st) : NAME##_k<32>(a_kmajor, b_kmajor, p, st);              \
     }
 

@@ -45,11 +45,12 @@ struct GemmParams {
     int debug;        // timing-ablation flags (gnk_set_debug_flags): 1 = no LDS-DMA in the main loop, 2 = no MFMA, 4 = no LDS reads
 };
 
-// KB_: k per scale block of the tile-scaled epilogue (128: one block per K-step; 64 / 32: Jetfire-style blocks, 2 / 4 per step)
+// KB_: k per scale block of the tile-scaled epilogue (128: one block per K-step; 64 / 32: Jetfire-style blocks, 2 / 4 per step;
+// 256 stands for ANY multiple of 128 above 128: GemmParams::kgroup K-steps per block, a run-time number)
 template <int BM_, int BN_, int WM_, int WN_, bool AK_, bool BK_, int OP_, int FA_, int FB_, int EPI_, int KB_ = GNK_BK>
 struct GemmCfg {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, KB = KB_;
-    static_assert(KB_ == 128 || ((KB_ == 64 || KB_ == 32) && EPI_ == 2), "scale blocks of 64 / 32 k exist for the tile-scaled epilogue only");
+    static_assert(KB_ == 128 || ((KB_ == 64 || KB_ == 32 || KB_ == 256) && EPI_ == 2), "scale blocks other than 128 k exist for the tile-scaled epilogue only");
     static constexpr bool A_KMAJOR = AK_, B_KMAJOR = BK_;
     static constexpr int OP = OP_, FA = FA_, FB = FB_, EPI = EPI_;
     static constexpr int NW = WM * WN, NT = NW * 64;
@@ -618,13 +619,15 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
     // with one element per thread and load, k fastest (coalesced for row-major sA), once per 8 steps.
     // Scale blocks of Cfg::KB k: NB per 128-k step.  "Scale step" u = t * NB + b indexes sA[:, u] / sB[u, :]; the panel holds 8 of them.
     constexpr int TS_STEPS = 8, TS_PE = Cfg::EPI == EPI_TILE ? Cfg::BM * TS_STEPS / Cfg::NT : 1;
-    constexpr int NB = GNK_BK / Cfg::KB, PS = TS_STEPS / NB;    // PS: K-steps per panel
+    constexpr bool MULTI = Cfg::KB > GNK_BK;                    // scale blocks of kgroup * 128 k (its own instances: the run-time group
+                                                                // logic cost the plain 128-k kernel 4 %)
+    constexpr int NB = MULTI ? 1 : GNK_BK / Cfg::KB, PS = TS_STEPS / NB;    // PS: K-steps per panel
     // NB > 1: the B-side scales go through a second panel ([scale step][BN columns]) too -- NB x NTL per-lane values for this step
     // and as many in flight for the next one spilled registers.
     constexpr bool PANEL_B = NB > 1;
     constexpr int TS_PEB = PANEL_B ? Cfg::BN * TS_STEPS / Cfg::NT : 1;
     const int nk = (int)(p.K / GNK_BK);
-    const int G = Cfg::EPI == EPI_TILE && NB == 1 && p.kgroup > 1 ? p.kgroup : 1;   // K-steps per scale block (QK = G * 128)
+    const int G = MULTI && p.kgroup > 1 ? p.kgroup : 1;                             // K-steps per scale block (QK = G * 128)
     const int nks = (nk * NB + G - 1) / G;                                          // scale steps along K
     const int psteps = PS * G;                                                      // K-steps covered by one panel
     TileScaleIdx<Cfg> ts;
@@ -686,6 +689,9 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
         sa.issue(As0, wave);
         sb.issue(Bs0, wave);
     }
+    // scale bookkeeping as running counters (wave-uniform; divisions by the run-time G cost ~5 % of the tile-scaled fp8 kernel):
+    // c_gph = t % G, c_u = t / G (scale step), c_tk = t % psteps, c_tsi = c_tk / G, c_pn = t / psteps (panel number)
+    int c_gph = 0, c_u = 0, c_tk = 0, c_tsi = 0, c_pn = 0;
     for (int t = 0; t < nk; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -695,17 +701,16 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
         float sbv1[Cfg::EPI == EPI_TILE && !PANEL_B ? NTL : 1];
         int tsi = 0;
         if constexpr (Cfg::EPI == EPI_TILE) {
-            const int tk = t % psteps;
-            tsi = tk / G;              // scale step of this K-step within the panel (times NB)
-            if (tk == 0) {             // the panel of the next 8 scale steps was fetched during the step before it (or before the loop)
+            tsi = c_tsi;               // scale step of this K-step within the panel (times NB)
+            if (c_tk == 0) {           // the panel of the next 8 scale steps was fetched during the step before it (or before the loop)
                 panel_store();
                 __syncthreads();
             }
             if constexpr (!PANEL_B) {
                 TileScaleIdx<Cfg>::convert_b(p, raw_b, sbv1);
-                if (t + 1 < nk) ts.load_raw_b(p, (t + 1) / G, raw_b);
+                if (t + 1 < nk) ts.load_raw_b(p, c_u + (c_gph + 1 == G ? 1 : 0), raw_b);
             }
-            if (tk == psteps - 1 && t + 1 < nk) panel_fetch((t + 1) / psteps);
+            if (c_tk == psteps - 1 && t + 1 < nk) panel_fetch(c_pn + 1);
         }
 
         const int cur = t & 1;
@@ -722,9 +727,9 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
             for (int b = 0; b < NB; ++b) {
                 if constexpr (NB == 1) {
                     // QK = G * 128: the partial sum runs over G steps (exact in int32) and is rescaled after the last of them
-                    if (G == 1 || t % G == 0) compute_step<Cfg, true>(As0 + cur * Cfg::A_BYTES, Bs0 + cur * Cfg::B_BYTES, acc, wm, wn, lane);
+                    if (!MULTI || c_gph == 0) compute_step<Cfg, true>(As0 + cur * Cfg::A_BYTES, Bs0 + cur * Cfg::B_BYTES, acc, wm, wn, lane);
                     else compute_step<Cfg, false>(As0 + cur * Cfg::A_BYTES, Bs0 + cur * Cfg::B_BYTES, acc, wm, wn, lane);
-                    if (G > 1 && (t + 1) % G != 0) continue;
+                    if (MULTI && c_gph + 1 != G) continue;
                 } else {
 #pragma unroll
                     for (int s2 = 0; s2 < Cfg::KB / 32; ++s2)
@@ -757,6 +762,8 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
                         }
                     }
             }
+            if (++c_gph == G) { c_gph = 0; ++c_u; ++c_tsi; }
+            if (++c_tk == psteps) { c_tk = 0; c_tsi = 0; ++c_pn; }
         }
     }
 
@@ -769,7 +776,7 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
 
 template <class Cfg> int launch(const GemmParams &p0, hipStream_t st) {
     constexpr int LDS_TOTAL = Cfg::LDS_BYTES + ScalePrefetch<Cfg::BM, Cfg::BN, Cfg::NT, Cfg::EPI>::BYTES + (Cfg::EPI == EPI_TILE ? Cfg::BM * 8 * 4 : 0) +
-                              (Cfg::EPI == EPI_TILE && Cfg::KB != GNK_BK ? Cfg::BN * 8 * 4 : 0);   // tile-scaled: A-side scale panel (+ B-side panel for 64 / 32-k blocks)
+                              (Cfg::EPI == EPI_TILE && Cfg::KB < GNK_BK ? Cfg::BN * 8 * 4 : 0);   // tile-scaled: A-side scale panel (+ B-side panel for 64 / 32-k blocks)
     GemmParams p = p0;
     p.grid_m = (int)((p.M + Cfg::BM - 1) / Cfg::BM);
     p.grid_n = (int)((p.N + Cfg::BN - 1) / Cfg::BN);
