@@ -7,6 +7,8 @@ sees an opaque, functional node.
 """
 from __future__ import annotations
 
+import threading
+
 import torch
 from torch import Tensor
 
@@ -22,6 +24,7 @@ lib.define("quantize_int8_rowwise_colmax(Tensor x, bool stochastic_rounding, flo
 lib.define("quantize_int8_colwise_given(Tensor x, Tensor absmax, bool stochastic_rounding, float eps) -> (Tensor, Tensor)")
 
 _sr_calls = 0   # advances the Philox offset between stochastic-rounding calls
+_sr_lock = threading.Lock()
 
 
 def supports(x: Tensor, dim: int) -> bool:
@@ -51,7 +54,6 @@ def _quantize_int8_meta(x: Tensor, dim: int, stochastic_rounding: bool, eps: flo
 
 @torch.library.impl(lib, "quantize_int8", "CUDA")
 def _quantize_int8_hip(x: Tensor, dim: int, stochastic_rounding: bool, eps: float):
-    global _sr_calls
     if not supports(x, dim):
         raise RuntimeError(f"gn_kernels::quantize_int8: unsupported input (shape {tuple(x.shape)}, strides {x.stride()}, "
                            f"dim {dim}, dtype {x.dtype})")
@@ -74,11 +76,7 @@ def _quantize_int8_hip(x: Tensor, dim: int, stochastic_rounding: bool, eps: floa
     L = _cabi.load()
     ws_bytes = L.gnk_quantize_int8_workspace_bytes(R, C, sxr, sxc)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
-    seed = offset = 0
-    if stochastic_rounding:
-        seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
-        offset = (_sr_calls << 40) & 0xFFFFFFFFFFFFFFFF
-        _sr_calls += 1
+    seed, offset = _sr_args(stochastic_rounding)
     with _cabi.device_of(x):
         rc = L.gnk_quantize_int8(x.data_ptr(), _cabi.DTYPE_CODE[x.dtype], R, C, sxr, sxc, q.data_ptr(), sqr, sqc,
                                  scale.data_ptr(), eps, int(stochastic_rounding), seed, offset,
@@ -94,13 +92,15 @@ def _dense(x: Tensor) -> bool:
 
 # ------------------------------------------------------------------------------ fused dual-direction quantization
 def _sr_args(stochastic_rounding: bool):
+    """(seed, offset) of one stochastic-rounding call: every call gets its own 2^40-element slice of the Philox stream.  Forward runs
+    on the caller's thread and backward on the autograd engine's, so the call counter is taken under a lock."""
     global _sr_calls
     if not stochastic_rounding:
         return 0, 0
-    seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
-    offset = (_sr_calls << 40) & 0xFFFFFFFFFFFFFFFF
-    _sr_calls += 1
-    return seed, offset
+    with _sr_lock:
+        calls = _sr_calls
+        _sr_calls += 1
+    return torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, (calls << 40) & 0xFFFFFFFFFFFFFFFF
 
 
 def supports_rowwise_colmax(x: Tensor) -> bool:
