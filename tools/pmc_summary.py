@@ -19,7 +19,7 @@ for sub in sorted(p for p in root.iterdir() if p.is_dir()):
         for r in csv.DictReader(open(kt)):
             dur[r["Kernel_Name"][:60]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     for k, cs in vals.items():
-        if "gemm" not in k:
+        if "gemm" not in k and "quant" not in k and "absmax" not in k:
             continue
         d = statistics.median(dur[k]) if dur.get(k) else float("nan")
         print(f"[{sub.name}] {k}  n={len(next(iter(cs.values())))}  median duration {d:.1f} us")
