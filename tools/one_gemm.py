@@ -1,5 +1,5 @@
 """One GEMM configuration in a loop, for rocprofv3 (kernel trace or PMC passes).
-usage: python3 tools/one_gemm.py [i8|f8] [nt|nn|tn] [K] [iters] [variant]"""
+usage: python3 tools/one_gemm.py [i8|f8] [nt|nn|tn] [K] [iters] [variant] [tile block: 0 = row/col scales, 128 = (1, 128, 128) blocks, 32 / 64 = square blocks]"""
 import sys
 from pathlib import Path
 
@@ -26,6 +26,10 @@ else:
     B = lay(torch.randn(K, S, device="cuda").to(torch.float8_e4m3fn), bcm)
 rs = torch.randn(S, 1, device="cuda").div(128).bfloat16()
 cs = torch.randn(1, S, device="cuda").div(128).bfloat16()
+blk = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+if blk:
+    rs = torch.randn(S if blk == 128 else S // blk, K // blk, device="cuda").div(128).bfloat16()
+    cs = torch.randn(K // blk, S // blk, device="cuda").div(128).bfloat16()
 _cabi.load().gnk_set_gemm_variant(variant)
 for _ in range(iters):
     gn_kernels.scaled_mm(A, B, rs, cs)
