@@ -730,6 +730,19 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
                     if (!MULTI || c_gph == 0) compute_step<Cfg, true>(As0 + cur * Cfg::A_BYTES, Bs0 + cur * Cfg::B_BYTES, acc, wm, wn, lane);
                     else compute_step<Cfg, false>(As0 + cur * Cfg::A_BYTES, Bs0 + cur * Cfg::B_BYTES, acc, wm, wn, lane);
                     if (MULTI && c_gph + 1 != G) continue;
+                } else if constexpr (Cfg::OP == OP_I8 && Cfg::KB == 64) {
+                    // int8, 64-k blocks: one 64-k MFMA per tile on the usual 16-byte fragments of half b (the 32-k MFMA occupies the
+                    // matrix pipe just as long for half the work)
+                    const char *As = As0 + cur * Cfg::A_BYTES, *Bs = Bs0 + cur * Cfg::B_BYTES;
+                    v4i fa[MT], fb[NTL];
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j) fb[j] = load_frag<Cfg::B_KMAJOR, Cfg::BN>(Bs, wn * Cfg::WTN + 16 * j, b, lane);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) fa[i] = load_frag<Cfg::A_KMAJOR, Cfg::BM>(As, wm * Cfg::WTM + 16 * i, b, lane);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NTL; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb[j], fa[i], (v4i){0, 0, 0, 0}, 0, 0, 0);
                 } else {
 #pragma unroll
                     for (int s2 = 0; s2 < Cfg::KB / 32; ++s2)
