@@ -212,12 +212,22 @@ int gnk_bitnet_unpack_i2(const void *x, int64_t nbytes, void *out, void *stream)
 int gnk_set_gemm_variant(int variant);
 
 /*
- * Timing-ablation hook (no reference counterpart; results are WRONG while bits 0-3 are set).  Bits 0-3 act on the
- * 8-phase 256 x 256 GEMM kernel only (variant 4): 1 drops the main loop's LDS-DMA loads, 2 the MFMAs, 4 the LDS fragment
- * reads, 8 the whole epilogue.  Bit 4 (16) makes the quantize kernels use plain instead of nontemporal stores (results
- * unchanged).  Used by tools/ablate*.py and train_bench.py --gnk_debug_flags to attribute time.  Returns the previous flags.
+ * gnk_quantize_int8 for callers that CANNOT allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference, whose quantize_int8 (subclasses/int8.py:12-26) is
+ * eager ATen and allocates freely.  Same arguments and results as gnk_quantize_int8, bit for bit, minus the workspace:
+ * the fp32 absmax words a strided reduction needs between its two kernels live in a GNK_NOALLOC_SCRATCH_BYTES buffer
+ * inside the library's code object (one copy per GPU, held until the process ends).  The call performs no hipMalloc /
+ * hipFree and calls no allocating routine.  Limits: a strided reduction (sxc != 1) over more than
+ * gnk_quantize_int8_noalloc_max_rows() = GNK_NOALLOC_SCRATCH_BYTES / 4 logical rows is rejected with
+ * GNK_ERR_UNSUPPORTED; calls that overlap on one GPU (different streams or threads) share the buffer and RACE --
+ * serialise them, or use gnk_quantize_int8 with one workspace per stream.  The words used are cleared on `stream` at
+ * the start of each call.
  */
-int gnk_set_debug_flags(int flags);
+#define GNK_NOALLOC_SCRATCH_BYTES (256 * 1024)
+int64_t gnk_quantize_int8_noalloc_max_rows(void);
+int gnk_quantize_int8_noalloc(const void *x, int x_dtype, int64_t R, int64_t C, int64_t sxr, int64_t sxc,
+                              int8_t *q, int64_t sqr, int64_t sqc, void *scale, float eps,
+                              int sr, uint64_t seed, uint64_t offset, void *stream);
 
 #ifdef __cplusplus
 }

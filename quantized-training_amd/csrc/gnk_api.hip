@@ -8,7 +8,9 @@
 // ------------------------------------------------------------------ error plumbing
 static thread_local char g_err[512] = "";
 static thread_local int g_forced_variant = -1;
+#ifdef GNK_ABLATE
 static thread_local int g_debug_flags = 0;
+#endif
 
 int gnk_fail(int code, const char *fmt, ...) {
     va_list ap;
@@ -26,7 +28,9 @@ int gnk_check_launch(const char *what) {
 
 static int g_cus[64];
 
+#ifdef GNK_ABLATE
 int gnk_debug_flags_get(void) { return g_debug_flags; }
+#endif
 
 int gnk_num_cus(void) {
     int dev = 0;
@@ -47,7 +51,7 @@ extern "C" int gnk_init(void) {
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return gnk_fail(GNK_ERR_LAUNCH, "no HIP device is visible: libgnk_hip.so has no CPU path");
     gnk_num_cus();
-    return GNK_OK;
+    return gnk_quantize_noalloc_setup();   // device address of the built-in scratch buffer, once per device
 }
 
 extern "C" int gnk_set_gemm_variant(int variant) {
@@ -56,11 +60,14 @@ extern "C" int gnk_set_gemm_variant(int variant) {
     return old;
 }
 
+#ifdef GNK_ABLATE
+// Timing-ablation hook of ABLATE builds only (results are WRONG while bits 0-3 are set; bits listed in tools/ablate.py).
 extern "C" int gnk_set_debug_flags(int flags) {
     const int old = g_debug_flags;
     g_debug_flags = flags;
     return old;
 }
+#endif
 
 // ------------------------------------------------------------------ GEMM dispatch
 namespace {
@@ -263,7 +270,7 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
     p.M = c.M; p.N = c.N; p.K = c.K; p.lda = la.ld; p.ldb = lb.ld;
     p.ssam = c.ssam; p.ssak = c.ssak; p.ssbk = c.ssbk; p.ssbn = c.ssbn; p.QM = c.QM; p.QN = c.QN;
     p.out_dtype = c.out_dtype; p.scale_dtype = c.scale_dtype; p.col_scalar = c.col_scalar; p.order = c.order;
-    p.debug = g_debug_flags;
+    p.debug = gnk_debug_flags_get();
     p.kgroup = c.epi == EPI_TILE && c.QK > GNK_BK ? (int)(c.QK / GNK_BK) : 1;
     if (c.epi == EPI_TILE && c.QK != GNK_BK) {   // Jetfire-style blocks / blocks of several K-steps: the 32-k MFMA instances of the 128 x 128 kernel
         if (op == OP_I8) return gnk_launch_tkb_i8((int)c.QK, la.kmajor, lb.kmajor, p, st);

@@ -20,7 +20,16 @@ typedef unsigned short us8 __attribute__((ext_vector_type(8)));
 // ---------------------------------------------------------------- host-side error plumbing
 int gnk_fail(int code, const char *fmt, ...);   // records a thread-local message, returns code
 int gnk_check_launch(const char *what);        // hipGetLastError -> GNK_ERR_LAUNCH
-int gnk_debug_flags_get(void);                  // timing-experiment flags of the calling thread (gnk_set_debug_flags)
+// Timing-ablation flags (some make results WRONG on purpose) exist only in builds made with -DGNK_ABLATE (`make ABLATE=1`,
+// tools/ablate*.py); the released library has neither the setter nor the tests in its kernels.
+#ifdef GNK_ABLATE
+int gnk_debug_flags_get(void);                  // flags of the calling thread (gnk_set_debug_flags)
+#define GNK_DEBUG_BITS(v) (v)
+#else
+static inline int gnk_debug_flags_get(void) { return 0; }
+#define GNK_DEBUG_BITS(v) 0
+#endif
+int gnk_quantize_noalloc_setup(void);          // gnk_quantize.hip: per-device hipGetSymbolAddress of its scratch array (idempotent)
 int gnk_num_cus(void);                         // CU count of the current device (cached)
 
 static inline bool gnk_is_float_dtype(int d) { return d == GNK_BF16 || d == GNK_F16 || d == GNK_F32; }

@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) m
             scb[j][0] = (int)(((unsigned)w[0] >> sh) & 0xffu);
             scb[j][1] = (int)(((unsigned)w[1] >> sh) & 0xffu);
         }
-        if (ts == PSTEPS - 1 && t + 1 < nk && !(p.debug & 128)) panel_fetch((t + 1) / PSTEPS);   // debug flag 128: timing only
+        if (ts == PSTEPS - 1 && t + 1 < nk && !(GNK_DEBUG_BITS(p.debug) & 128)) panel_fetch((t + 1) / PSTEPS);   // debug flag 128: timing only
         const int cur = t & 1;
         if (t + 1 < nk) {
             sa.issue(As0 + (cur ^ 1) * Cfg::A_BYTES, wave);
@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(512) mxfp4_256_kernel(const MxParams mp) {
         ssrc = idx < 256 ? mp.sa + g * mp.ldsa : mp.sb + g * mp.ldsb;
     }
     auto issue_stage = [&](int st) {                            // stage st -> buffer st & 3; every fourth stage brings its panel
-        if ((st & 3) == 0 && !(p.debug & 128)) {   // debug flag 128 (timing only, wrong results): no scale traffic
+        if ((st & 3) == 0 && !(GNK_DEBUG_BITS(p.debug) & 128)) {   // debug flag 128 (timing only, wrong results): no scale traffic
             __builtin_amdgcn_global_load_lds((const GNK_GLOBAL void *)ssrc, (GNK_LDS void *)(Sbuf + ((st >> 2) & 1) * MX256_PNL + wave * 1024), 16, 0, 0);
             ssrc += 16;
         }
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(512) mxfp4_256_kernel(const MxParams mp) {
     v4i fa[8], fb[4];
     int sca[8], scb[4];
     const int r = lane & 15, g = lane >> 4;
-    const bool no_scale_reads = p.debug & 1024;   // debug flag 1024 (timing only): unit scales instead of the LDS panel reads
+    const bool no_scale_reads = GNK_DEBUG_BITS(p.debug) & 1024;   // debug flag 1024 (timing only): unit scales instead of the LDS panel reads
     auto load_frags = [&](int st) {
         const char *As = Abuf + (st & 3) * MX256_OPER, *Bs = Bbuf + (st & 3) * MX256_OPER, *Ss = Sbuf + ((st >> 2) & 1) * MX256_PNL + 4 * (st & 3);
 #pragma unroll

@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(const GemmParams p) {
     if (wm == 1) __builtin_amdgcn_s_barrier();           // stagger: group 1 runs one phase behind group 0
     __builtin_amdgcn_sched_barrier(0);
 
-    const int dbg = p.debug;
+    const int dbg = GNK_DEBUG_BITS(p.debug);
     int t = 0;
     for (; t + 1 < nk; t += 2) {
         K::template kstep<0>(smem, t, nk, acc, fa, fb, sa, sb, wave, wm, wn, lane, dbg);

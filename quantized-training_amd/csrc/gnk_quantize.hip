@@ -12,6 +12,8 @@
 //   * generic  : any strides / alignment / dtype, one block per logical row (slow, correct).
 #include "gnk_common.h"
 
+#include <mutex>
+
 namespace {
 
 template <int DT> struct ElemTraits;
@@ -653,6 +655,51 @@ extern "C" int gnk_quantize_int8(const void *x, int x_dtype, int64_t R, int64_t 
         hipLaunchKernelGGL((quant_generic_kernel<false>), dim3(grid), dim3(256), 0, st, x, x_dtype, q, scale, R, C, sxr, sxc,
                            sqr, sqc, eps, seed, offset);
     return gnk_check_launch("quantize_int8 generic");
+}
+
+// ---- the entry point that allocates nothing (include/gnk.h: gnk_quantize_int8_noalloc) ---------------------------
+// The strided reduction needs one fp32 absmax word per logical row between its two kernels.  gnk_quantize_int8 takes
+// that buffer from the caller; here it lives in the code object: every GPU that loads the library holds its own copy
+// of `scratch` (GNK_NOALLOC_SCRATCH_BYTES, until the process ends) at its own address.  In host code the array's name
+// is only a handle: the device address comes from hipGetSymbolAddress, once per device, and is what the kernels and
+// hipMemsetAsync receive.
+static __device__ __align__(256) unsigned char scratch[GNK_NOALLOC_SCRATCH_BYTES];
+static void *g_scratch_ptr[64];
+static std::mutex g_scratch_mu;
+
+// Called by gnk_init() (gnk_api.hip) with the device current; idempotent.
+int gnk_quantize_noalloc_setup(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        return gnk_fail(GNK_ERR_LAUNCH, "quantize_int8_noalloc: cannot identify the current device");
+    std::lock_guard<std::mutex> guard(g_scratch_mu);
+    if (g_scratch_ptr[dev]) return GNK_OK;
+    void *ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr)
+        return gnk_fail(GNK_ERR_LAUNCH, "quantize_int8_noalloc: hipGetSymbolAddress(scratch) failed on device %d: %s", dev, hipGetErrorString(e));
+    g_scratch_ptr[dev] = ptr;
+    return GNK_OK;
+}
+
+extern "C" int64_t gnk_quantize_int8_noalloc_max_rows(void) { return GNK_NOALLOC_SCRATCH_BYTES / 4; }
+
+extern "C" int gnk_quantize_int8_noalloc(const void *x, int x_dtype, int64_t R, int64_t C, int64_t sxr, int64_t sxc,
+                                         int8_t *q, int64_t sqr, int64_t sqc, void *scale, float eps, int sr, uint64_t seed,
+                                         uint64_t offset, void *stream) {
+    const int64_t need = gnk_quantize_int8_workspace_bytes(R, C, sxr, sxc);
+    if (need > (int64_t)GNK_NOALLOC_SCRATCH_BYTES)
+        return gnk_fail(GNK_ERR_UNSUPPORTED, "quantize_int8_noalloc: a strided reduction over %lld logical rows needs %lld bytes of scratch, "
+                        "the built-in buffer holds %lld (at most %lld rows): use gnk_quantize_int8 with a caller workspace",
+                        (long long)R, (long long)need, (long long)GNK_NOALLOC_SCRATCH_BYTES, (long long)(GNK_NOALLOC_SCRATCH_BYTES / 4));
+    int rc = gnk_init();              // runs gnk_quantize_noalloc_setup() for the current device (no allocation: a symbol look-up)
+    if (rc) return rc;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !g_scratch_ptr[dev])
+        return gnk_fail(GNK_ERR_LAUNCH, "quantize_int8_noalloc: no scratch address for the current device");
+    void *ptr = g_scratch_ptr[dev];   // the DEVICE address; never the array's name
+    // launch_colwise clears the words it uses (hipMemsetAsync on `stream`) before pass 1, so the previous call's maxima do not leak
+    return gnk_quantize_int8(x, x_dtype, R, C, sxr, sxc, q, sqr, sqc, scale, eps, sr, seed, offset, ptr, GNK_NOALLOC_SCRATCH_BYTES, stream);
 }
 
 // ---- fused dual-direction entry points (include/gnk.h) ---------------------------------------------------------

@@ -48,6 +48,8 @@ def load() -> ctypes.CDLL:
     L.gnk_quantize_int8.argtypes = [vp, ci, i64, i64, i64, i64, vp, i64, i64, vp, f32, ci, u64, u64, vp, i64, vp]
     L.gnk_quantize_int8_workspace_bytes.argtypes = [i64, i64, i64, i64]
     L.gnk_quantize_int8_workspace_bytes.restype = i64
+    L.gnk_quantize_int8_noalloc.argtypes = [vp, ci, i64, i64, i64, i64, vp, i64, i64, vp, f32, ci, u64, u64, vp]
+    L.gnk_quantize_int8_noalloc_max_rows.restype = i64
     L.gnk_quantize_int8_rowwise_colmax_workspace_bytes.argtypes = [ci, i64, i64]
     L.gnk_quantize_int8_rowwise_colmax_workspace_bytes.restype = i64
     L.gnk_quantize_int8_rowwise_colmax.argtypes = [vp, ci, i64, i64, i64, vp, i64, vp, vp, f32, ci, u64, u64, vp, i64, vp]
