@@ -41,9 +41,9 @@ def quantize_int8(tensor: Tensor, stochastic_rounding: bool = False, *, dim: int
     scale = amax|x| / 127 (fp32), data = clip(round(x / max(scale, eps)), -128, 127); with
     `stochastic_rounding` the rounding is floor(x / scale + U[0, 1)).
     """
-    if tensor.is_cuda and _qop.supports(tensor, dim):
+    if _qop.on_device(tensor) and _qop.supports(tensor, dim):
         return _qop.quantize_int8(tensor, stochastic_rounding, dim=dim, eps=eps)
-    if tensor.is_cuda and tensor.ndim >= 1:
+    if _qop.on_device(tensor) and tensor.ndim >= 1:
         # N-D device tensor reduced along an inner dim: move `dim` last, quantize, move back
         moved = tensor.movedim(dim, -1).contiguous()
         q, s = _qop.quantize_int8(moved, stochastic_rounding, dim=-1, eps=eps)

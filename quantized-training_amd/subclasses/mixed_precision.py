@@ -16,6 +16,7 @@ results are bit-identical to the reference's.
 from __future__ import annotations
 
 import threading
+import weakref
 from typing import NamedTuple
 
 import torch
@@ -108,20 +109,24 @@ class MixedPrecisionLinearWeight(Tensor):
 # ---------------------------------------------------------------------------------------------------------------------
 # Quantization plan of one Linear (device tensors).  The reference quantizes X, W and dY along BOTH dims every step,
 # each time from scratch (:100-108 called from :154, :178, :186), and q_proj / k_proj / v_proj (gate / up) re-quantize
-# the very same activation; under torch.compile Inductor merges those duplicates.  Without a tracing compiler the same
-# is done here explicitly -- identical arithmetic on identical inputs, so results do not change:
-#   * a small identity-keyed cache (storage address, offset, shape, strides, dtype, version counter; the source tensor
-#     is held so the address cannot be recycled) returns the int8 copy of a tensor that was already quantized along
-#     that dim.  Off under stochastic rounding: every call must draw its own random numbers.  ACTIVATIONS ONLY: the
-#     optimizer updates a wrapped weight through __torch_dispatch__, below the layer that bumps version counters, so
-#     the inner bf16 weight's counter never moves and a weight must be re-quantized every time;
+# the very same activation; under torch.compile (llm_pretrain.py:184) the compiler's common-subexpression pass merges
+# those duplicates.  Identical arithmetic on identical inputs either way, so results do not change:
 #   * for large tensors the row-wise pass also collects the fp32 column absmax (gn_kernels::quantize_int8_rowwise_colmax),
 #     which backward hands to the column-wise pass (gn_kernels::quantize_int8_colwise_given): one read instead of two.
+#     Every decision is taken from shapes, strides and dtypes only, so the plan traces under torch.compile;
+#   * EAGER MODE ONLY (never while a compiler traces: the traced graph is de-duplicated by the compiler itself): a small
+#     cache returns the int8 copy of an ACTIVATION that was already quantized along that dim.  An entry is keyed by the
+#     identity of the tensor OBJECT handed to F.linear (weak reference + version counter), so it dies with the
+#     activation, pins nothing but its int8 copy, and is only made for tensors produced inside an autograd graph
+#     (`grad_fn` set): those are fresh objects every forward, so no entry outlives a step, and a leaf the user may rewrite
+#     through `.data` between two forwards is never cached.  Off under stochastic rounding (every call draws its own
+#     random numbers), for inference tensors (no version counter) and for weights (the optimizer updates a wrapped weight
+#     through __torch_dispatch__, below the layer that bumps version counters).
 _FUSED_MIN_NUMEL = 48 * 1024 * 1024   # measured (tools/fused_quant_probe.py): the fused pair wins from ~32768 x 2048 up
-_CACHE_SLOTS = 4
+_CACHE_SLOTS = 8                      # int8 copies alive at once (LRU); q/k/v and gate/up need 1-2
 _cache_enabled = True
 _fused_enabled = True
-_cache: dict = {}
+_cache: dict = {}                     # id(source) -> [weakref(source), version, {kind: value}]
 _cache_lock = threading.Lock()        # forward runs on the caller's thread, backward on the autograd engine's
 
 
@@ -138,61 +143,78 @@ def set_quantize_plan(*, cache: bool | None = None, fused: bool | None = None) -
 
 
 def clear_quantize_cache() -> None:
-    """Drop the cached int8 copies (and the activations they pin); e.g. at the end of a step when memory is tight."""
+    """Drop the cached int8 copies."""
     with _cache_lock:
         _cache.clear()
 
 
-def _key(kind: str, t: Tensor):
-    return (kind, t.data_ptr(), t.storage_offset(), tuple(t.shape), t.stride(), t.dtype, t._version, t.device.index)
+def _cacheable(src: Tensor | None, sr: bool) -> bool:
+    if src is None or sr or not _cache_enabled or torch.compiler.is_compiling():
+        return False
+    return src.grad_fn is not None and not src.is_inference()
 
 
-def _cache_get(kind: str, t: Tensor, sr: bool):
-    if sr or not _cache_enabled:
+def _cache_get(kind: str, src: Tensor | None, sr: bool):
+    if not _cacheable(src, sr):
         return None
     with _cache_lock:
-        hit = _cache.get(_key(kind, t))
-    return hit[1] if hit is not None else None
+        ent = _cache.get(id(src))
+        if ent is None:
+            return None
+        if ent[0]() is not src or ent[1] != src._version:     # the id was recycled, or the tensor was written since
+            del _cache[id(src)]
+            return None
+        return ent[2].get(kind)
 
 
-def _cache_put(kind: str, t: Tensor, sr: bool, value):
-    if sr or not _cache_enabled:
+def _cache_put(kind: str, src: Tensor | None, sr: bool, value) -> None:
+    if not _cacheable(src, sr):
         return
+    key = id(src)
+
+    def _gone(_ref, key=key):
+        with _cache_lock:
+            ent = _cache.get(key)
+            if ent is not None and ent[0] is _ref:
+                del _cache[key]
+
     with _cache_lock:
-        while len(_cache) >= 2 * _CACHE_SLOTS:
-            _cache.pop(next(iter(_cache)))               # dicts keep insertion order: drop the oldest
-        _cache[_key(kind, t)] = (t, value)               # holding t pins its memory, so the key cannot alias a new tensor
+        ent = _cache.get(key)
+        if ent is None or ent[0]() is not src or ent[1] != src._version:
+            while len(_cache) >= _CACHE_SLOTS:
+                _cache.pop(next(iter(_cache)))               # dicts keep insertion order: drop the oldest
+            ent = _cache[key] = [weakref.ref(src, _gone), src._version, {}]
+        ent[2][kind] = value
 
 
 def _plan_ok(*ts: Tensor) -> bool:
-    return all(t.is_cuda and t.ndim == 2 and t.stride(1) == 1 and t.numel() > 0 for t in ts)
+    return all(_qop.on_device(t) and t.ndim == 2 and t.stride(1) == 1 and t.numel() > 0 for t in ts)
 
 
-def _q_rows(x: Tensor, sr: bool, want_colmax: bool, cache: bool = True):
-    """quantize_int8(x, dim=1) -> (int8, scale (R, 1), fp32 column absmax or None)."""
-    stochastic, sr = sr, sr or not cache          # for the cache, "stochastic" and "do not cache" are the same thing
-    hit = _cache_get("row", x, sr)
+def _q_rows(x: Tensor, sr: bool, want_colmax: bool, src: Tensor | None = None):
+    """quantize_int8(x, dim=1) -> (int8, scale (R, 1), fp32 column absmax or None).  `src`: the tensor object x was reshaped from
+    (cache identity); None = do not cache (weights)."""
+    hit = _cache_get("row", src, sr)
     if hit is not None and (hit[2] is not None or not want_colmax):
         return hit
     if want_colmax and _fused_enabled and x.numel() >= _FUSED_MIN_NUMEL and _qop.supports_rowwise_colmax(x):
-        out = _qop.quantize_int8_rowwise_colmax(x, stochastic)
+        out = _qop.quantize_int8_rowwise_colmax(x, sr)
     else:
-        out = (*quantize_int8(x, stochastic, dim=1), None)
-    _cache_put("row", x, sr, out)
+        out = (*quantize_int8(x, sr, dim=1), None)
+    _cache_put("row", src, sr, out)
     return out
 
 
-def _q_cols(x: Tensor, sr: bool, colmax: Tensor | None, cache: bool = True):
+def _q_cols(x: Tensor, sr: bool, colmax: Tensor | None, src: Tensor | None = None):
     """quantize_int8(x, dim=0) -> (int8 in x's layout, scale (1, C)); `colmax` (if known) saves the absmax pass."""
-    stochastic, sr = sr, sr or not cache
-    hit = _cache_get("col", x, sr)
+    hit = _cache_get("col", src, sr)
     if hit is not None:
         return hit
     if colmax is not None and _qop.supports_colwise_given(x):
-        out = _qop.quantize_int8_colwise_given(x, colmax, stochastic)
+        out = _qop.quantize_int8_colwise_given(x, colmax, sr)
     else:
-        out = quantize_int8(x, stochastic, dim=0)
-    _cache_put("col", x, sr, out)
+        out = quantize_int8(x, sr, dim=0)
+    _cache_put("col", src, sr, out)
     return out
 
 
@@ -214,7 +236,7 @@ def _dynamic_mm(A: Tensor, B: Tensor, sr: bool, dtype: str) -> Tensor:
 
 class _Int8MixedPrecisionLinear(torch.autograd.Function):
     """reference :146-193.  Combined forward(ctx, ...) form (the reference uses forward + setup_context): the column
-    absmax collected by forward's row-wise passes travels to backward on ctx."""
+    absmax collected by forward's row-wise passes is saved for backward beside the bf16 tensors."""
 
     @staticmethod
     def forward(ctx, input: Tensor, weight: MixedPrecisionLinearWeight, bias: Tensor | None = None):
@@ -226,8 +248,8 @@ class _Int8MixedPrecisionLinear(torch.autograd.Function):
             x2d = input.reshape(-1, w.shape[1])
             if cfg.dtype == "int8" and _plan_ok(x2d, w):
                 sr = cfg.stochastic_rounding
-                xq, xs, x_cm = _q_rows(x2d, sr, cfg.grad_weight and ctx.needs_input_grad[1])
-                wq, ws, w_cm = _q_rows(w, sr, cfg.grad_input and ctx.needs_input_grad[0], cache=False)
+                xq, xs, x_cm = _q_rows(x2d, sr, cfg.grad_weight and ctx.needs_input_grad[1], input)
+                wq, ws, w_cm = _q_rows(w, sr, cfg.grad_input and ctx.needs_input_grad[0])
                 out = scaled_mm(xq, wq.T, xs, ws.T)                                                # A @ B.T
             else:
                 out = _dynamic_mm(x2d, w.T, cfg.stochastic_rounding, cfg.dtype)
@@ -235,16 +257,16 @@ class _Int8MixedPrecisionLinear(torch.autograd.Function):
         else:
             out = input @ w.T
         ctx.config = cfg
-        ctx.save_for_backward(input, w)       # bf16 tensors; int8 copies are re-derived in backward (reference :160-165)
-        ctx.colmax = (x_cm, w_cm)
+        # bf16 tensors; int8 copies are re-derived in backward (reference :160-165).  The two small fp32 column-absmax vectors (or None)
+        # travel the same way, so that a tracing compiler sees them as saved tensors
+        ctx.save_for_backward(input, w, x_cm, w_cm)
         ctx.bias = bias is not None
         return out + bias if bias is not None else out
 
     @staticmethod
     def backward(ctx, grad_output):
-        input, weight = ctx.saved_tensors
+        input, weight, x_cm, w_cm = ctx.saved_tensors
         cfg = ctx.config
-        x_cm, w_cm = ctx.colmax
         sr = cfg.stochastic_rounding
         grad_input = grad_weight = grad_bias = None
 
@@ -259,7 +281,7 @@ class _Int8MixedPrecisionLinear(torch.autograd.Function):
         if want_gi:
             if cfg.grad_input and plan:
                 gq, gs, g_cm = _q_rows(go2d, sr, want_gw and cfg.grad_weight)
-                wq, ws = _q_cols(weight, sr, w_cm, cache=False)
+                wq, ws = _q_cols(weight, sr, w_cm)
                 grad_input = scaled_mm(gq, wq, gs, ws)                                             # A @ B
             elif cfg.grad_input:
                 grad_input = _dynamic_mm(go2d, weight, sr, cfg.dtype)
@@ -269,7 +291,7 @@ class _Int8MixedPrecisionLinear(torch.autograd.Function):
 
         if want_gw:
             if cfg.grad_weight and plan:
-                xq, xs = _q_cols(x2d, sr, x_cm)                  # == quantize_int8(x2d.T, dim=1), transposed
+                xq, xs = _q_cols(x2d, sr, x_cm, input)           # == quantize_int8(x2d.T, dim=1), transposed
                 gq0, gs0 = _q_cols(go2d, sr, g_cm)
                 grad_weight = scaled_mm(xq.T, gq0, xs.T, gs0).T                                    # (A.T @ B).T
             elif cfg.grad_weight:

@@ -43,11 +43,24 @@ def oracle_cpu_ops():
     def int8_mm_cpu(A, B):
         return oracle.int8_mm(A, B)
 
-    def quantize_cpu(x, dim, sr, eps):
-        return oracle.quantize_int8(x, sr, dim=dim, eps=eps)
+    def _sr(sr, rng):
+        return dict(seed=int(rng.item()), offset=0) if sr else {}
+
+    def quantize_cpu(x, dim, sr, eps, rng=None):
+        return oracle.quantize_int8(x, sr, dim=dim, eps=eps, **_sr(sr, rng))
+
+    def rowwise_colmax_cpu(x, sr, eps, rng=None):
+        q, s = oracle.quantize_int8(x, sr, dim=1, eps=eps, **_sr(sr, rng))
+        return q, s, x.float().abs().amax(0)
+
+    def colwise_given_cpu(x, absmax, sr, eps, rng=None):
+        assert torch.equal(absmax, x.float().abs().amax(0)), "colwise_given: the absmax handed over is not the column absmax of x"
+        return oracle.quantize_int8(x, sr, dim=0, eps=eps, **_sr(sr, rng))
 
     impl.impl("scaled_mm", scaled_mm_cpu, "CPU")
     impl.impl("tile_scaled_mm", scaled_mm_cpu, "CPU")
     impl.impl("int8_mm", int8_mm_cpu, "CPU")
     impl.impl("quantize_int8", quantize_cpu, "CPU")
+    impl.impl("quantize_int8_rowwise_colmax", rowwise_colmax_cpu, "CPU")
+    impl.impl("quantize_int8_colwise_given", colwise_given_cpu, "CPU")
     yield impl

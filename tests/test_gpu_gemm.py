@@ -372,3 +372,124 @@ def test_full_size_4096_jetfire_blocks(layout):
     assert torch.equal(gn_kernels.scaled_mm(A, B, sA * 2, sB), out * 2)        # power-of-two scaling commutes with every rounding
     outh = gn_kernels.scaled_mm(A, B, sA.bfloat16(), sB.bfloat16())
     assert outh.dtype is torch.bfloat16 and torch.isfinite(outh.float()).all()
+
+
+# ------------------------------------------------------------------------------- round-2 parity gaps
+def _scaled_ref(A, B, sa, sb):
+    """scaled_mm_ref of benchmark_mm.py:46-50 in fp32 on the device (row / column / 2-D tile scales alike)."""
+    M, K = A.shape
+    N = B.shape[1]
+    a = A.float() * sa.float().repeat_interleave(M // sa.shape[0], 0).repeat_interleave(K // sa.shape[1], 1) if sa.shape[1] > 1 else A.float() * sa.float()
+    b = B.float() * sb.float().repeat_interleave(K // sb.shape[0], 0).repeat_interleave(N // sb.shape[1], 1) if sb.shape[0] > 1 else B.float() * sb.float()
+    return a @ b
+
+
+def _unwidened_failures(got, want32):
+    """Elements the REFERENCE's own check would reject: torch.testing.assert_close(bf16, bf16) defaults, rtol 1.6e-2, atol 1e-5
+    (benchmark_mm.py:128-145), against the bf16-rounded fp32 product."""
+    want = want32.bfloat16().float()
+    return int(((got.float() - want).abs() > 1.6e-2 * want.abs() + 1e-5).sum().item())
+
+
+def _record(name, value):
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(path):
+        f = os.path.join(path, "fp8_unwidened_counts.json")
+        data = json.load(open(f)) if os.path.exists(f) else {}
+        data[name] = value
+        json.dump(data, open(f, "w"), indent=1, sort_keys=True)
+    print(f"[fp8 unwidened assert_close] {name}: {value}")
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+def test_full_size_4096_fp8_scaled_all_layouts(layout):
+    """benchmark_mm.py's FP8 inputs at 4096^3 in A@B.T, A@B and A.T@B: every output against scaled_mm_ref (fp32 on the device) under the
+    stated tolerance, and the COUNT of elements the reference's unwidened assert_close would reject (reported)."""
+    torch.manual_seed(2025 * 2024)
+    S = 4096
+    acm, bcm = LAYOUTS[layout]
+    A = to_layout(torch.randn(S, S, device=DEV).to(torch.float8_e4m3fn), acm)
+    B = to_layout(torch.randn(S, S, device=DEV).to(torch.float8_e4m3fn), bcm)
+    rs = torch.randn(S, 1, device=DEV).div(128).bfloat16()
+    cs = torch.randn(1, S, device=DEV).div(128).bfloat16()
+    out = gn_kernels.scaled_mm(A, B, rs, cs)
+    want = _scaled_ref(A, B, rs, cs)
+    mag = (A.float().abs() * rs.float().abs()) @ (B.float().abs() * cs.float().abs())
+    bound = 1.6e-2 * want.abs() + 5e-5 * mag + 1e-5
+    assert not bool(((out.float() - want).abs() > bound).any())
+    _record(f"scaled_fp8_4096_{layout}", {"failing": _unwidened_failures(out, want), "of": S * S})
+    plain = gn_kernels._triton_mm(A, B, out_dtype=torch.bfloat16)
+    wantp = A.float() @ B.float()
+    magp = A.float().abs() @ B.float().abs()
+    assert not bool(((plain.float() - wantp).abs() > 1.6e-2 * wantp.abs() + 5e-5 * magp + 1e-5).any())
+    _record(f"plain_fp8_4096_{layout}", {"failing": _unwidened_failures(plain, wantp), "of": S * S})
+
+
+@pytest.mark.parametrize("style", ["deepseek", "jetfire"])
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+def test_full_size_4096_fp8_tile_scaled(style, layout):
+    """Tile-scaled FP8 at 4096^3, DeepSeek-style (1 x 128 / 128 x 128) and Jetfire-style (32^3) blocks: whole output against
+    scaled_mm_ref under the stated fp8 tolerance; sampled row blocks against the CPU oracle's ascending-K-block accumulation."""
+    torch.manual_seed(2025 * 2024 + 3)
+    S = 4096
+    acm, bcm = LAYOUTS[layout]
+    A = to_layout(torch.randn(S, S, device=DEV).to(torch.float8_e4m3fn), acm)
+    B = to_layout(torch.randn(S, S, device=DEV).to(torch.float8_e4m3fn), bcm)
+    if style == "deepseek":
+        sA = to_layout(torch.randn(S, S // 128, device=DEV).div(128).bfloat16(), acm)      # benchmark_mm.py:88-96
+        sB = to_layout(torch.randn(S // 128, S // 128, device=DEV).div(128).bfloat16(), bcm)
+        qm = 1
+    else:
+        sA = torch.randn(S // 32, S // 32, device=DEV).div(128).bfloat16()
+        sB = torch.randn(S // 32, S // 32, device=DEV).div(128).bfloat16()
+        qm = 32
+    out = gn_kernels.scaled_mm(A, B, sA, sB)
+    assert out.dtype is torch.bfloat16
+    want = _scaled_ref(A, B, sA, sB)
+    K = S
+    a_abs = A.float().abs() * sA.float().abs().repeat_interleave(S // sA.shape[0], 0).repeat_interleave(K // sA.shape[1], 1)
+    b_abs = B.float().abs() * sB.float().abs().repeat_interleave(K // sB.shape[0], 0).repeat_interleave(S // sB.shape[1], 1)
+    mag = a_abs @ b_abs
+    bound = 1.6e-2 * want.abs() + 5e-5 * mag + 1e-5
+    assert not bool(((out.float() - want).abs() > bound).any())
+    _record(f"tile_fp8_4096_{style}_{layout}", {"failing": _unwidened_failures(out, want), "of": S * S})
+    # oracle on one block of rows over 256 columns (fp8 decode + fp32 partial sums + the three-rounding rescale on the host)
+    r0 = 97 * 32
+    rows = slice(r0, r0 + 32)
+    srows = slice(r0 // qm, r0 // qm + 32 // qm)
+    nb = 256 // (S // sB.shape[1])
+    wo = oracle.scaled_mm(A[rows].cpu().contiguous(), B[:, :256].cpu(), sA[srows].cpu().contiguous(), sB[:, :nb].cpu().contiguous())
+    assert_fp8_close(out[rows][:, :256], wo, mag[rows][:, :256].cpu())
+
+
+@pytest.mark.parametrize("S", [1024, 2048])
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+def test_auto_dispatch_at_benchmark_mid_sizes(S, layout):
+    """1024^3 and 2048^3 of benchmark_mm.py go through plan_gemm's OTHER choices (128 x 128 tiles, split-K): int8 bit-exact against the
+    oracle on sampled rows and against the unfused epilogue everywhere; fp8 within the stated tolerance everywhere."""
+    torch.manual_seed(2025 * 2024 + S)
+    acm, bcm = LAYOUTS[layout]
+    A = to_layout(torch.randint(-128, 127, (S, S), dtype=torch.int8, device=DEV), acm)
+    B = to_layout(torch.randint(-128, 127, (S, S), dtype=torch.int8, device=DEV), bcm)
+    rs = torch.randn(S, 1, device=DEV).div(128).bfloat16()
+    cs = torch.randn(1, S, device=DEV).div(128).bfloat16()
+    C = gn_kernels.int8_mm(A, B)
+    rows = torch.randperm(S)[:32].sort().values.to(DEV)
+    assert torch.equal(C[rows].cpu(), oracle.int8_mm(A[rows].cpu().contiguous(), B.cpu()))
+    assert torch.equal(C.sum(0, dtype=torch.int64), (A.sum(0, dtype=torch.int64).double() @ B.double()).to(torch.int64))
+    out = gn_kernels.scaled_mm(A, B, rs, cs)
+    assert bits_equal(out, ((C.float() * rs.float()) * cs.float()).bfloat16())
+    assert bits_equal(out[rows], oracle.scaled_mm(A[rows].cpu().contiguous(), B.cpu(), rs[rows].cpu().contiguous(), cs.cpu()))
+    tsA = to_layout(torch.randn(S, S // 128, device=DEV).div(128).bfloat16(), acm)
+    tsB = to_layout(torch.randn(S // 128, S // 128, device=DEV).div(128).bfloat16(), bcm)
+    outt = gn_kernels.scaled_mm(A, B, tsA, tsB)
+    assert bits_equal(outt[rows], oracle.scaled_mm(A[rows].cpu().contiguous(), B.cpu(), tsA[rows].cpu().contiguous(), tsB.cpu()))
+    A8 = to_layout(torch.randn(S, S, device=DEV).to(torch.float8_e4m3fn), acm)
+    B8 = to_layout(torch.randn(S, S, device=DEV).to(torch.float8_e4m3fn), bcm)
+    out8 = gn_kernels.scaled_mm(A8, B8, rs, cs)
+    want8 = _scaled_ref(A8, B8, rs, cs)
+    mag8 = (A8.float().abs() * rs.float().abs()) @ (B8.float().abs() * cs.float().abs())
+    assert not bool(((out8.float() - want8).abs() > 1.6e-2 * want8.abs() + 5e-5 * mag8 + 1e-5).any())
+    _record(f"scaled_fp8_{S}_{layout}", {"failing": _unwidened_failures(out8, want8), "of": S * S})

@@ -6,7 +6,7 @@ import pytest
 import torch
 from torch import nn
 
-from subclasses import (Int8QTConfig, MixedPrecisionConfig, MixedPrecisionLinearWeight, convert_int8_quantized_training,
+from subclasses import (Int8LinearWeight, Int8QTConfig, MixedPrecisionConfig, MixedPrecisionLinearWeight, convert_int8_quantized_training,
                         convert_mixed_precision)
 from tests._util import bits_equal, load, t_from_bits
 
@@ -146,20 +146,75 @@ def test_training_step_runs_and_learns():
     assert losses[-1] < losses[0] * 0.9, losses
 
 
-def test_int8_linear_weight_dynamic_activation_on_gpu():
+def _peek_sr_key():
+    """The Philox key the NEXT stochastic-rounding call will draw from torch's CPU generator (gn_kernels/quantize.py:draw_rng)."""
+    from gn_kernels import quantize as qmod
+
+    state = torch.get_rng_state()
+    key = int(qmod.draw_rng(True).item())
+    torch.set_rng_state(state)
+    return key
+
+
+@pytest.mark.parametrize("activation", ["int8", "int8_sr"])
+def test_int8_linear_weight_dynamic_forward_bit_exact_vs_oracle(activation):
+    """reference subclasses/int8.py:144-158 (with the scale-shape drift repaired): out = scaled_mm(q(x), W_i8.T, x_scale,
+    W.scale.T) + bias -- every piece is bit-reproducible on the host: oracle.quantize_int8 (Philox replay under int8_sr), oracle.scaled_mm."""
+    import oracle
+
     torch.manual_seed(1)
     ref = nn.Linear(256, 128).to(BF).to(DEV)
-    lin = convert_int8_quantized_training(copy.deepcopy(ref), config=Int8QTConfig(activation="int8"))
-    x = torch.randn(64, 256, device=DEV, dtype=BF, requires_grad=True)
+    lin = convert_int8_quantized_training(copy.deepcopy(ref), config=Int8QTConfig(activation=activation))
+    w = lin.weight
+    wq, wscale = oracle.quantize_int8(ref.weight.detach().cpu(), dim=1)                 # from_float: int8.py:83-87
+    assert torch.equal(w.int_data.cpu(), wq) and bits_equal(w.scale, wscale)
+    x = torch.randn(4, 16, 256, device=DEV, dtype=BF, requires_grad=True)
+    key = _peek_sr_key()
     out = lin(x)
-    torch.testing.assert_close(out, ref(x), atol=0.1, rtol=0.1)
-    out.float().square().mean().backward()
-    opt = torch.optim.AdamW(lin.parameters(), lr=1e-2, foreach=False)
-    opt.step()                                   # SR re-quantization through the HIP kernel
-    assert lin.weight.int_data.dtype is torch.int8
+    sr = activation == "int8_sr"
+    xq, xs = oracle.quantize_int8(x.detach().cpu().view(-1, 256), sr, dim=1, seed=key if sr else 0, offset=0)
+    want = oracle.scaled_mm(xq, wq.T, xs, wscale.T.contiguous()) + ref.bias.detach().cpu()
+    assert bits_equal(out.view(-1, 128), want)
+    torch.testing.assert_close(out, ref(x), atol=0.1, rtol=0.1)                         # and it is a Linear
+    # backward stays bf16 (int8.py:170,177): grad_input = (gy * scale.T) @ W_i8, grad_weight = gy.T @ x
+    gy = torch.randn_like(out)
+    out.backward(gy)
+    want_gi = (gy * w.scale.T) @ w.int_data.to(BF)
+    assert bits_equal(x.grad, want_gi)
 
 
-def test_train_bench_int8_mixed_precision_step_runs_on_the_gpu():
+def test_int8_linear_weight_sr_copy_bit_exact_vs_oracle_philox_replay():
+    """reference subclasses/int8.py:114-133: an optimizer-style in-place update de-quantizes, updates, and re-quantizes INTO the int8
+    storage with stochastic rounding.  The device result must equal the host replay of the same Philox stream bit for bit."""
+    import oracle
+
+    torch.manual_seed(2)
+    W = torch.randn(128, 256, dtype=BF)
+    w = Int8LinearWeight.from_float(W.to(DEV))
+    new = (torch.randn(128, 256) * 0.7).to(BF)
+    key = _peek_sr_key()
+    w.copy_(new.to(DEV))                                                                # aten.copy_ -> quantize_int8(src, stochastic_rounding=True)
+    qo, so = oracle.quantize_int8(new, True, dim=1, seed=key, offset=0)
+    assert torch.equal(w.int_data.cpu(), qo) and bits_equal(w.scale, so)
+    # AdamW-style update through the dispatch table: w.add_(delta) = copy_(dequantize(w) + delta)
+    delta = (torch.randn(128, 256) * 1e-3).to(BF)
+    deq = (qo * so.view(-1, 1)).add_(delta)                                             # the same ATen ops on the host (exactly rounded bf16)
+    key = _peek_sr_key()
+    w.add_(delta.to(DEV))
+    qo2, so2 = oracle.quantize_int8(deq, True, dim=1, seed=key, offset=0)
+    assert torch.equal(w.int_data.cpu(), qo2) and bits_equal(w.scale, so2)
+    # and a real optimizer step keeps the storage int8 and moves it
+    lin = convert_int8_quantized_training(nn.Linear(256, 128).to(BF).to(DEV), config=Int8QTConfig(activation="int8"))
+    before = lin.weight.int_data.clone()
+    lin(torch.randn(64, 256, device=DEV, dtype=BF)).float().square().mean().backward()
+    torch.optim.AdamW(lin.parameters(), lr=1e-2, foreach=False).step()
+    assert lin.weight.int_data.dtype is torch.int8 and not torch.equal(lin.weight.int_data, before)
+
+
+@pytest.mark.parametrize("model,bs,seq,extra", [("tiny", 2, 256, []), ("tiny", 2, 256, ["--compile"]),
+                                                ("470m", 4, 2048, [])],          # BASELINE configs[3] at its real size (Llama-2-470m, 4 x 2048 tokens)
+                         ids=["tiny", "tiny-compiled", "llama-2-470m"])
+def test_train_bench_int8_mixed_precision_step_runs_on_the_gpu(model, bs, seq, extra):
     """End to end: transformers Llama (tiny) -> convert_mixed_precision -> gn_kernels ops -> HIP kernels -> AdamW, through
     the harness the tok/s numbers come from; the INT8 loss must track the bf16 loss of the same seed."""
     import json
@@ -170,8 +225,8 @@ def test_train_bench_int8_mixed_precision_step_runs_on_the_gpu():
     root = Path(__file__).resolve().parent.parent
     losses = {}
     for q in ("none", "mixed_precision"):
-        r = subprocess.run([sys.executable, str(root / "train_bench.py"), "--model", "tiny", "--quantize", q, "--batch_size", "2", "--seq_len", "256",
-                            "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600)
+        r = subprocess.run([sys.executable, str(root / "train_bench.py"), "--model", model, "--quantize", q, "--batch_size", str(bs), "--seq_len", str(seq),
+                            "--steps", "2", "--warmup", "1"] + extra, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         assert out["value"] > 0

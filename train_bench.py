@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--log_losses", action="store_true", help="record the loss of every step (adds one host sync per step: not for throughput numbers)")
     ap.add_argument("--no_quantize_cache", action="store_true", help="A/B: re-quantize a tensor every time it is used (subclasses.mixed_precision.set_quantize_plan)")
     ap.add_argument("--no_fused_quantize", action="store_true", help="A/B: never use the fused row-wise + column-absmax kernels")
-    ap.add_argument("--gnk_debug_flags", type=int, default=0, help="A/B timing switches of libgnk_hip.so (gnk_set_debug_flags)")
+    ap.add_argument("--compile", action="store_true", help="loss_fn = torch.compile(get_loss), as llm_pretrain.py:184 (the gn_kernels ops stay opaque nodes)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -93,10 +93,6 @@ def main():
         from subclasses import mixed_precision as _mp
 
         _mp.set_quantize_plan(cache=not args.no_quantize_cache, fused=not args.no_fused_quantize)
-    if args.gnk_debug_flags:
-        from gn_kernels import _cabi
-
-        _cabi.load().gnk_set_debug_flags(args.gnk_debug_flags)
     qkw = json.loads(args.quantize_kwargs)
     if args.quantize == "mixed_precision":
         from subclasses import MixedPrecisionConfig, convert_mixed_precision
@@ -133,9 +129,11 @@ def main():
                 t[:, i] = torch.where(keep[:, i], perm[t[:, i - 1]], noise[:, i])
         return t[:, :-1].contiguous(), t[:, 1:].contiguous()
 
+    loss_fn = torch.compile(get_loss) if args.compile else get_loss     # llm_pretrain.py:184
+
     def step():
         tokens, labels = batch()
-        loss = get_loss(model, tokens, labels)
+        loss = loss_fn(model, tokens, labels)
         loss.backward()
         optim.step()
         optim.zero_grad()
@@ -174,7 +172,7 @@ def main():
                 args.quantize, "bf16 weights/activations; int8 MFMA in the Linear fwd / grad-input / grad-weight"),
             "data": "synthetic tokens, random-init weights",
             "config": {"workload": f"llama-{args.model} {'(ASSUMED 1.1B shape: 2048/5632/22/32)' if args.model == '1b' else ''} global_batch {args.batch_size} x seq_len {args.seq_len}, "
-                                   f"quantize={args.quantize}{' ' + args.quantize_kwargs if qkw else ''}, AdamW, {'DDP x%d (RCCL all-reduce)' % world if world > 1 else 'single GPU'}",
+                                   f"quantize={args.quantize}{' ' + args.quantize_kwargs if qkw else ''}, {'torch.compile(get_loss)' if args.compile else 'eager'}, AdamW, {'DDP x%d (RCCL all-reduce)' % world if world > 1 else 'single GPU'}",
                        "params": n_params, "body_linear_weights": lin},
             "body_linear_TOPS": round(6 * args.batch_size * args.seq_len * lin * args.steps / dt * 1e-12, 1),
             "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)],
