@@ -116,27 +116,116 @@ def time_kernel_graph(fn, per_graph=20, replays=6):
     return ts[len(ts) // 2]
 
 
-def cpu_baseline(S=4096, budget_s=12.0):
-    """The reference's CPU path (benchmark_mm.py:41, uncompiled): torch._int_mm + fp32 scale + cast, on
-    the same 4096^3 A@B.T problem.  Imported from oracle/ -- the checker, timed as a baseline only."""
+def _median_time(fn, budget_s, max_runs=20, warm=2):
+    for _ in range(warm):
+        fn()
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while (time.perf_counter() < t_end and len(times) < max_runs) or len(times) < 3:
+        t0 = time.perf_counter()
+        fn()
+        times.append(time.perf_counter() - t0)
+    return sorted(times)[len(times) // 2], len(times)
+
+
+def cpu_baseline(budget_s=20.0):
+    """The reference's CPU path, as BASELINE.md section 4 plans it (configs[0]): quantize_int8 of both operands (subclasses/int8.py:12-26
+    in ATen ops), torch._int_mm, fp32 dequant scale -> bf16 (benchmark_mm.py:41, uncompiled), at S = 1024 / 2048 / 4096, each leg
+    timed separately on the host cores torch was given.  Imported from oracle/ -- the checker, timed as a baseline only.
+    `value` is the full path at 4096^3 (the size the GPU metric is quoted on)."""
     from oracle import torch_ref
 
     torch.manual_seed(2025 * 2024)
-    A = torch.randint(-128, 127, (S, S), dtype=torch.int8)
-    B = torch.randint(-128, 127, (S, S), dtype=torch.int8).T.contiguous().T
-    sA = torch.randn(S, 1).div(128).bfloat16()
-    sB = torch.randn(1, S).div(128).bfloat16()
-    torch_ref.scaled_mm_intmm(A, B, sA, sB)
-    times = []
-    t_end = time.perf_counter() + budget_s
-    while time.perf_counter() < t_end and len(times) < 20:
-        t0 = time.perf_counter()
-        torch_ref.scaled_mm_intmm(A, B, sA, sB)
-        times.append(time.perf_counter() - t0)
-    med = sorted(times)[len(times) // 2]
-    return {"value": round(2 * S ** 3 / med * 1e-12, 4), "unit": "TOPS", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"scaled INT8 A@B.T {S}^3 via torch._int_mm + fp32 scale -> bf16 (reference fallback formula), "
-                      f"median of {len(times)} runs, {med * 1e3:.1f} ms each"}
+    legs = {}
+    full = {}
+    for S, share in ((1024, 0.1), (2048, 0.2), (4096, 0.7)):
+        A, W = torch.randn(S, S).bfloat16(), torch.randn(S, S).bfloat16()
+        A_i8, sa = torch_ref.quantize_int8(A, dim=1)
+        W_i8, sw = torch_ref.quantize_int8(W, dim=1)
+
+        def full_path():
+            a, s0 = torch_ref.quantize_int8(A, dim=1)
+            w, s1 = torch_ref.quantize_int8(W, dim=1)
+            return torch_ref.scaled_mm_intmm(a, w.T, s0, s1.T)
+
+        b = budget_s * share / 3
+        tq, nq = _median_time(lambda: torch_ref.quantize_int8(A, dim=1), b)
+        tm, nm = _median_time(lambda: torch._int_mm(A_i8, W_i8.T), b)
+        tf, nf = _median_time(full_path, b)
+        full[S] = tf
+        legs[str(S)] = {"quantize_one_operand_ms": round(tq * 1e3, 3), "quantize_GB/s_algorithmic": round((3 * S * S + 2 * S) / tq * 1e-9, 2),
+                        "int_mm_ms": round(tm * 1e3, 3), "int_mm_TOPS": round(2 * S ** 3 / tm * 1e-12, 3),
+                        "full_path_ms": round(tf * 1e3, 3), "full_path_TOPS": round(2 * S ** 3 / tf * 1e-12, 3), "runs": [nq, nm, nf]}
+    return {"value": legs["4096"]["full_path_TOPS"], "unit": "TOPS", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "configs[0] formula (2 x quantize_int8 in ATen + torch._int_mm + fp32 dequant scale -> bf16, the reference's fallback "
+                      "benchmark_mm.py:41 fed by subclasses/int8.py:12-26) on randn bf16 A, W at S = 1024 / 2048 / 4096, seed 2025*2024, "
+                      f"median of >= 3 runs per leg within a {budget_s:.0f} s budget; value = full path at 4096^3",
+            "legs": legs}
+
+
+def vendor_yardstick(cases, S):
+    """Same-box library yardsticks at 4096^3 (event-timed, same method as detail_tops): torch._int_mm and torch._scaled_mm go to
+    hipBLASLt, torch.mm (bf16) to hipBLASLt / rocBLAS.  They answer whether a vendor GEMM exceeds this repository's kernels on this chip
+    under the same clocks; each entry is TOPS or the reason the library refused the layout."""
+    out = {}
+
+    def t(name, fn):
+        try:
+            fn()
+            avg, _ = time_kernel(fn, iters=20)
+            out[name] = round(2 * S ** 3 / (avg * 1e-3) * 1e-12, 1)
+        except Exception as exc:
+            out[name] = f"refused: {type(exc).__name__}: {str(exc)[:120]}"
+
+    for lname in LAYOUTS:
+        A, B, sA, sB = cases[("int8", lname)]
+        t(f"torch._int_mm int8 {lname}", lambda A=A, B=B: torch._int_mm(A, B))
+        A8, B8, _, _ = cases[("fp8", lname)]
+        ra, cb = sA.float(), sB.float()
+        t(f"torch._scaled_mm fp8 rowwise-scaled {lname}", lambda A8=A8, B8=B8: torch._scaled_mm(A8, B8, scale_a=ra, scale_b=cb, out_dtype=torch.bfloat16))
+    one = torch.ones((), device=sA.device)
+    A8, B8, _, _ = cases[("fp8", "A@B.T")]
+    t("torch._scaled_mm fp8 tensorwise-scaled A@B.T", lambda: torch._scaled_mm(A8, B8, scale_a=one, scale_b=one, out_dtype=torch.bfloat16))
+    Ab = torch.randn(S, S, device=sA.device).bfloat16()
+    Bb = torch.randn(S, S, device=sA.device).bfloat16()
+    t("torch.mm bf16 A@B.T", lambda: torch.mm(Ab, Bb.T))
+    t("torch.mm bf16 A@B", lambda: torch.mm(Ab, Bb))
+    return out
+
+
+def train_detail(world, rank, quick=False):
+    """The tok/s half of BASELINE.json's metric, outside the timed region: Llama INT8 mixed-precision training steps through
+    train_bench.run (the harness restating llm_pretrain.py), torch.compile(get_loss) as the reference runs it, bf16 beside INT8-MP.
+    At N > 1 this is DDP over RCCL with the reference's GLOBAL batch of 16 sequences (strong scaling, llm_pretrain.py:93,151)."""
+    import gc
+
+    import train_bench
+
+    runs = [("llama-1b", ["--model", "1b", "--batch_size", "16"], 6, 2)]
+    if world == 1:
+        runs.insert(0, ("llama-2-470m", ["--model", "470m", "--batch_size", "4"], 10, 3))
+    res = {}
+    for name, margs, steps, warm in runs:
+        if quick:
+            steps, warm = 2, 1
+        for q in ("mixed_precision", "none"):
+            key = f"{name} {'int8_mp' if q == 'mixed_precision' else 'bf16'} compiled"
+            try:
+                torch._dynamo.reset()
+                a = train_bench.parse_args(margs + ["--quantize", q, "--steps", str(steps), "--warmup", str(warm), "--compile"])
+                r = train_bench.run(a)
+                if rank == 0:
+                    res[key] = {"tok/s": r["value"], "ms_per_step": r["ms_per_step"], "body_linear_TOPS": r["body_linear_TOPS"],
+                                "max_mem_GiB": r.get("max_mem_GiB"), "loss_first_last": r["loss_first_last"], "workload": r["config"]["workload"]}
+            except Exception as exc:   # detail only: never a reason to lose the bench line
+                if rank == 0:
+                    res[key] = f"failed: {type(exc).__name__}: {str(exc)[:200]}"
+            gc.collect()
+            torch.cuda.empty_cache()
+        a, b = res.get(f"{name} int8_mp compiled"), res.get(f"{name} bf16 compiled")
+        if isinstance(a, dict) and isinstance(b, dict):
+            res[f"{name} int8_mp / bf16"] = round(a["tok/s"] / b["tok/s"], 3)
+    return res
 
 
 def main():
@@ -146,6 +235,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-detail", action="store_true", help="skip the untimed per-kernel sweep")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--no-train", action="store_true", help="skip the untimed Llama training tok/s runs (detail_train)")
+    ap.add_argument("--quick-train", action="store_true", help="detail_train with 2 steps per run (smoke use)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -296,8 +387,16 @@ def main():
             except Exception as exc:   # detail only: never a reason to lose the bench line
                 nxt["error"] = f"{type(exc).__name__}: {exc}"
             out["detail_next_rows"] = nxt
+            out["detail_vendor_yardstick_4096_tops"] = vendor_yardstick(cases, S)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()
+    del cases
+    torch.cuda.empty_cache()
+    if not args.no_train:        # every rank takes part (DDP at N > 1); rank 0 reports
+        tr = train_detail(world, rank, quick=args.quick_train)
+        if rank == 0:
+            out["detail_train"] = tr
+    if rank == 0:
         print(json.dumps(out), flush=True)
 
     if world > 1:

@@ -30,3 +30,20 @@ def test_two_rank_ddp_over_gloo_splits_the_global_batch():
     assert r.returncode == 0, r.stderr[-2000:]
     out = _last_json(r.stdout)
     assert out["n_gpus"] == 2 and "DDP x2" in out["config"]["workload"] and out["value"] > 0
+
+
+def test_two_rank_ddp_int8_mixed_precision_compiled_over_gloo():
+    """configs[4]'s code path, rehearsed on the CPU: DDP(model) over gloo + torch.compile(get_loss) + MixedPrecisionLinearWeight
+    parameters (llm_pretrain.py:126-132,184).  The ops' CPU backend is the oracle (tests/_train_bench_oracle_worker.py, test-only);
+    both ranks must finish, agree on the averaged gradients' effect (same loss trajectory as the eager run) and report tok/s."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1"]
+    args = ["--model", "tiny", "--quantize", "mixed_precision", "--device", "cpu", "--seq_len", "32", "--steps", "2", "--warmup", "1", "--batch_size", "4"]
+    outs = {}
+    for tag, port, extra in (("eager", "29641", []), ("compiled", "29642", ["--compile", "--compile_backend", "aot_eager"])):
+        r = subprocess.run(base + ["--master-port", port, str(ROOT / "tests" / "_train_bench_oracle_worker.py"), *args, *extra],
+                           capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[tag] = _last_json(r.stdout)
+    assert outs["compiled"]["n_gpus"] == 2 and "torch.compile" in outs["compiled"]["config"]["workload"]
+    assert outs["compiled"]["loss_first_last"] == outs["eager"]["loss_first_last"]      # same ops on the same data: identical losses

@@ -53,7 +53,7 @@ def get_loss(model, tokens, labels):   # llm_pretrain.py:30-36
     return F.cross_entropy(logits.view(-1, logits.shape[-1]), labels.long().view(-1))
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="470m", choices=list(MODELS))
     ap.add_argument("--quantize", default="mixed_precision", choices=["none", "mixed_precision", "int8", "bitnet"])
@@ -71,8 +71,13 @@ def main():
     ap.add_argument("--no_quantize_cache", action="store_true", help="A/B: re-quantize a tensor every time it is used (subclasses.mixed_precision.set_quantize_plan)")
     ap.add_argument("--no_fused_quantize", action="store_true", help="A/B: never use the fused row-wise + column-absmax kernels")
     ap.add_argument("--compile", action="store_true", help="loss_fn = torch.compile(get_loss), as llm_pretrain.py:184 (the gn_kernels ops stay opaque nodes)")
-    args = ap.parse_args()
+    ap.add_argument("--compile_backend", default="inductor", help="torch.compile backend (tests use aot_eager on the CPU)")
+    return ap.parse_args(argv)
 
+
+def run(args):
+    """One measured training run; returns the result dict on rank 0 (None elsewhere).  Joins an already initialised process group
+    (bench.py calls this in-process after its own timed region) or creates one from the torchrun environment."""
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -80,7 +85,8 @@ def main():
     dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
     if on_gpu:
         torch.cuda.set_device(local_rank)
-    if world > 1:
+    own_group = world > 1 and not dist.is_initialized()
+    if own_group:
         dist.init_process_group(backend="nccl" if on_gpu else "gloo", **({"device_id": dev} if on_gpu else {}))
     assert args.batch_size % world == 0
     bsize = args.batch_size // world
@@ -129,7 +135,7 @@ def main():
                 t[:, i] = torch.where(keep[:, i], perm[t[:, i - 1]], noise[:, i])
         return t[:, :-1].contiguous(), t[:, 1:].contiguous()
 
-    loss_fn = torch.compile(get_loss) if args.compile else get_loss     # llm_pretrain.py:184
+    loss_fn = torch.compile(get_loss, backend=args.compile_backend) if args.compile else get_loss     # llm_pretrain.py:184
 
     def step():
         tokens, labels = batch()
@@ -162,6 +168,7 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+    out = None
     if rank == 0:
         toks = args.batch_size * args.seq_len * args.steps
         lin = sum(m.in_features * m.out_features for m in model.modules() if isinstance(m, nn.Linear) and m.out_features != 32000)
@@ -180,10 +187,17 @@ def main():
         }
         if on_gpu:
             out["max_mem_GiB"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
-        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+    if own_group:
         dist.destroy_process_group()
+    return out
+
+
+def main():
+    out = run(parse_args())
+    if out is not None:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
