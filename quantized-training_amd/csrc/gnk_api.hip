@@ -101,6 +101,10 @@ gnk_gemm_launcher pick_launcher(int op, int fa, int fb, int variant) {
                : variant == GNK_VARIANT_256_SIMPLE ? gnk_launch_i8_v3
                : variant == GNK_VARIANT_256_PP8 ? gnk_launch_i8_v4
                                                 : gnk_launch_i8_v1;
+    if (variant == GNK_VARIANT_256_PP8) {
+        static const gnk_gemm_launcher f8pp8[2][2] = {{gnk_launch_f8_00_v4, gnk_launch_f8_01_v4}, {gnk_launch_f8_10_v4, gnk_launch_f8_11_v4}};
+        return f8pp8[fa][fb];
+    }
     static const gnk_gemm_launcher f8[2][2][2] = {
         {{gnk_launch_f8_00_v0, gnk_launch_f8_00_v1}, {gnk_launch_f8_01_v0, gnk_launch_f8_01_v1}},
         {{gnk_launch_f8_10_v0, gnk_launch_f8_10_v1}, {gnk_launch_f8_11_v0, gnk_launch_f8_11_v1}}};
@@ -219,7 +223,7 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
         tile_ok = (c.QK % GNK_BK == 0 || c.QK == 64 || c.QK == 32) && c.QK / GNK_BK < (1 << 20) && c.K % c.QK == 0 && c.QN % 4 == 0 && c.N % 4 == 0 && c.ssam >= 0 && c.ssak >= 0 && c.ssbk >= 0 && c.ssbn >= 0 && amax < (1LL << 31) && bmax < (1LL << 31);
     }
     const bool ok_128 = fast_layout && c.K >= GNK_BK && c.K % GNK_BK == 0 && tile_ok;
-    if ((variant == GNK_VARIANT_256_SIMPLE || variant == GNK_VARIANT_256_PP8) && (op != OP_I8 || c.epi == EPI_TILE)) variant = GNK_VARIANT_256;
+    if ((variant == GNK_VARIANT_256_SIMPLE && op != OP_I8) || ((variant == GNK_VARIANT_256_SIMPLE || variant == GNK_VARIANT_256_PP8) && c.epi == EPI_TILE)) variant = GNK_VARIANT_256;
     if (variant == GNK_VARIANT_256 && c.epi == EPI_TILE) variant = GNK_VARIANT_128;
     int splits = 1;
     if (variant < 0 || variant > GNK_VARIANT_LAST) {
@@ -227,8 +231,10 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
         const GemmPlan plan = plan_gemm(c.M, c.N, c.K, ok_pp2, ok_128, can_split);
         variant = plan.variant;
         if (plan.splits > 1 && c.ws_bytes >= (int64_t)plan.splits * c.M * c.N * 4) splits = plan.splits;
-        // int8 with both operands K-major: the 8-phase kernel measured 3-5 % ahead of the 4-stage one (60.0 vs 64.0 us at 4096^3)
-        if (variant == GNK_VARIANT_256 && op == OP_I8 && la.kmajor && lb.kmajor && ok_128) variant = GNK_VARIANT_256_PP8;
+        // A K-major (A@B.T, A@B): the 8-phase kernel.  Measured at 4096^3 against the 4-stage one (tools/cmp_variants.py, round 2): int8
+        // A@B.T 54.0 vs 59.4 us, A@B 56.2 vs 57.5; fp8 (one 16x16x128 MFMA per tile and step instead of two 32x32x64) A@B.T 52.2 vs 59.4,
+        // A@B 54.1 vs 55.7.  A M-major (A.T@B) stays on the 4-stage kernel (fp8 55.3 vs 57.9, int8 level).
+        if (variant == GNK_VARIANT_256 && la.kmajor && ok_128) variant = GNK_VARIANT_256_PP8;
     } else if (variant != GNK_VARIANT_GENERIC && !(variant == GNK_VARIANT_256 ? ok_pp2 : ok_128)) {
         return gnk_fail(GNK_ERR_UNSUPPORTED, "%s: forced fast variant %d cannot take these strides / sizes", name, variant);
     }

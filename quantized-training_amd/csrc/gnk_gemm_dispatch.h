@@ -9,7 +9,8 @@
 //   1: 128 x 128 tile, 4 waves (2 x 2), two-buffer loop, 64 KiB LDS, 2 workgroups / CU    -- mid-size problems
 //   2: generic 64 x 64 kernel (any strides / sizes; the fallback)
 //   3: 256 x 256 tile, 8 waves, two-buffer loop (the first kernel; int8 only, kept for A/B timing)
-//   4: 256 x 256 tile, 8 waves, two 128-k buffers, 8-phase ping-pong (gnk_gemm_pp.h; int8 only, kept for A/B timing)
+//   4: 256 x 256 tile, 8 waves, two 128-k buffers, 8-phase ping-pong (gnk_gemm_pp.h): int8, and fp8 on the 16x16x128 MFMA;
+//      the heuristic's choice whenever A is K-major (A@B.T, A@B)
 enum { GNK_VARIANT_256 = 0, GNK_VARIANT_128 = 1, GNK_VARIANT_GENERIC = 2, GNK_VARIANT_256_SIMPLE = 3, GNK_VARIANT_256_PP8 = 4, GNK_VARIANT_LAST = 4 };
 
 // fp8 format codes as the MFMA's cbsz/blgp fields want them
@@ -24,6 +25,10 @@ GNK_DECLARE_LAUNCHER(gnk_launch_i8_v0);
 GNK_DECLARE_LAUNCHER(gnk_launch_i8_v1);
 GNK_DECLARE_LAUNCHER(gnk_launch_i8_v3);
 GNK_DECLARE_LAUNCHER(gnk_launch_i8_v4);
+GNK_DECLARE_LAUNCHER(gnk_launch_f8_00_v4);
+GNK_DECLARE_LAUNCHER(gnk_launch_f8_01_v4);
+GNK_DECLARE_LAUNCHER(gnk_launch_f8_10_v4);
+GNK_DECLARE_LAUNCHER(gnk_launch_f8_11_v4);
 GNK_DECLARE_LAUNCHER(gnk_launch_f8_00_v0);
 GNK_DECLARE_LAUNCHER(gnk_launch_f8_01_v0);
 GNK_DECLARE_LAUNCHER(gnk_launch_f8_10_v0);

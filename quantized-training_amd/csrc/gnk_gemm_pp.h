@@ -19,7 +19,7 @@
 // consecutive quadrants share an operand sub-tile:
 //     p0 MFMA q(0,0) | p1 read B1; DMA B-pieces of tile t+1 | p2 MFMA q(0,1) | p3 read A1
 //     p4 MFMA q(1,1) | p5 read B0; vmcnt(0): tile t+1 landed | p6 MFMA q(1,0)
-//     p7 read A0,B0 of tile t+1; DMA A-pieces of tile t+2 into tile t's buffer
+//     p7 read A0,B0 of tile t+1; DMA A-pieces of tile t+2 into tile t's buffer (K-major x K-major: in p5, behind the wait)
 // Buffer safety (2 LDS buffers): tile t is last read in p5 of either group (reads retired by
 // lgkmcnt(0) before the phase's barrier), and the first DMA into its buffer is issued in p7 of group 0,
 // one barrier later.  Tile t+1 is complete when every wave has passed its own vmcnt(0) in p5 and
@@ -35,6 +35,7 @@ template <class Cfg> struct PP {
     typedef typename AccT<Cfg::OP>::type acc_t;
     typedef Stager<Cfg::A_KMAJOR, 256, 8> StA;
     typedef Stager<Cfg::B_KMAJOR, 256, 8> StB;
+    static constexpr bool DMA_P5 = Cfg::A_KMAJOR && Cfg::B_KMAJOR;
 
     // Fragments are kept as 8-register tuples (k-substep 0 in elements 0-3, k-substep 1 in 4-7): exactly the
     // operand of the K=128 fp8 MFMA, and two sub-tuples for the K=64 int8 MFMA, so that no copy is needed
@@ -55,7 +56,6 @@ template <class Cfg> struct PP {
     }
     template <int QM, int QN>
     static __device__ __forceinline__ void mfma_q(acc_t (&acc)[8][4], const v8i (&fa)[4], const v8i (&fb)[2]) {
-        __builtin_amdgcn_s_setprio(1);
         if constexpr (Cfg::OP == OP_I8) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -81,7 +81,6 @@ template <class Cfg> struct PP {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(acc[QM * 4 + i][QN * 2 + j]));
-        __builtin_amdgcn_s_setprio(0);
     }
 
     static __device__ __forceinline__ void end_mfma_phase() {
@@ -116,6 +115,9 @@ template <class Cfg> struct PP {
         end_mfma_phase();
         if (rd) load_b<0>(Bs, fb, wn, lane);             // p5
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); //    this wave's pieces of tile t+1 have landed
+        // A-half of tile t+2 into tile t's A buffer (last read in p3 of either group).  Both operands K-major: issued here, behind the
+        // wait, where the phase carries 4 fragment reads (p7 carries 12): 1-2 % at 4096^3; the M/N-major forms showed no gain and keep p7
+        if (DMA_P5 && t + 2 < nk && dma) sa.issue(As, wave);
         end_load_phase();
         if (mma) mfma_q<1, 0>(acc, fa, fb);              // p6
         end_mfma_phase();
@@ -123,7 +125,7 @@ template <class Cfg> struct PP {
             load_a<0>(An, fa, wm, lane);
             load_b<0>(Bn, fb, wn, lane);
         }
-        if (t + 2 < nk && dma) sa.issue(As, wave);       //    first half of tile t+2 into tile t's buffer
+        if (!DMA_P5 && t + 2 < nk && dma) sa.issue(As, wave);   //    first half of tile t+2 into tile t's buffer
         end_load_phase();
     }
 };
@@ -171,6 +173,9 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(const GemmParams p) {
     K::template load_b<0>(B0, fb, wn, lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    // Static priority for the later-dispatched half of the workgroup (waves 4-7 lose every issue arbitration on their SIMD otherwise),
+    // set once: measured 1-2 % ahead of raising the priority around every MFMA cluster (MI355X_MICROARCH.md, "Two waves per SIMD", item 4).
+    if (wm == 1) __builtin_amdgcn_s_setprio(1);
     if (wm == 1) __builtin_amdgcn_s_barrier();           // stagger: group 1 runs one phase behind group 0
     __builtin_amdgcn_sched_barrier(0);
 

@@ -4,11 +4,13 @@ or a call fails, the op raises."""
 from __future__ import annotations
 
 import ctypes
+import os
 from pathlib import Path
 
 import torch
 
-_LIB_PATH = Path(__file__).resolve().parent / "libgnk_hip.so"
+# GNK_LIBRARY: tuning only (an A/B build of the same sources, e.g. `make ABLATE=1 OUT=...`); the shipped library is the default
+_LIB_PATH = Path(os.environ.get("GNK_LIBRARY") or Path(__file__).resolve().parent / "libgnk_hip.so")
 ABI_VERSION = 1
 
 BF16, F16, F32, I8, E4M3, E5M2, I32 = range(7)

@@ -43,7 +43,7 @@ def main(ks=(256, 1024, 4096, 8192), variants=None):
                 L.gnk_set_gemm_variant(v)
                 t = timeit(lambda: gn_kernels.scaled_mm(A, B, rs, cs))
                 out.append(f"i8 {vn} {t:7.1f}us {2*S*S*K/t/1e6:6.0f}T")
-                if vn != "pp8":
+                if True:
                     t = timeit(lambda: gn_kernels.scaled_mm(A8, B8, rs, cs))
                     out.append(f"f8 {vn} {t:7.1f}us {2*S*S*K/t/1e6:6.0f}T")
             L.gnk_set_gemm_variant(-1)
@@ -51,4 +51,4 @@ def main(ks=(256, 1024, 4096, 8192), variants=None):
 
 
 if __name__ == "__main__":
-    main()
+    main(ks=tuple(int(k) for k in sys.argv[1:]) or (256, 1024, 4096, 8192))
