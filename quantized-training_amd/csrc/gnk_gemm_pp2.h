@@ -8,7 +8,7 @@
 //   * a STAGE is 64 k (A 256 x 64 B + B 256 x 64 B = 32 KiB); four stages live in LDS, so three stages of
 //     LDS-DMA are in flight behind the one being read (>= 4 phases, ~1 us, of latency tolerance);
 //   * a stage is consumed in TWO phases: one group of four waves issues its whole stage of MFMAs
-//     (16 x v_mfma_i32_32x32x32_i8 or 8 x v_mfma_scale_f32_32x32x64_f8f6f4 = 512 matrix-pipe cycles) while
+//     (32 x v_mfma_i32_16x16x64_i8 or 8 x v_mfma_scale_f32_32x32x64_f8f6f4 = 512 matrix-pipe cycles) while
 //     the other group reads its next stage's fragments (12 x ds_read_b128 / 24 x ds_read_b64_tr_b8),
 //     issues its share of the LDS-DMA for stage s+4 and waits for stage s+2 -- 4 barriers per 128 k;
 //   * MFMA shapes whose K divides the 64-k stage: int8 v_mfma_i32_16x16x64_i8 (32 per wave and stage),

@@ -1,8 +1,9 @@
 """FP8 matmul operators kept under the reference's CUTLASS op names
 (kernels/gn_kernels/cutlass_mm.py:17-20,36-47,59-77; csrc/cutlass_sm89_fp8.cu, cutlass_sm120a_fp8.cu).
 
-On MI355X they run on the same LDS-DMA MFMA kernel family as `scaled_mm`, using
-v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (OCP e4m3fn / e5m2 are native on gfx950).
+On MI355X they run on the same LDS-DMA MFMA kernel family as `scaled_mm`: the scaled MFMAs with unit block scales (OCP e4m3fn /
+e5m2 are native on gfx950) -- v_mfma_scale_f32_16x16x128_f8f6f4 in the 8-phase 256 x 256 and the 128 x 128 kernels,
+v_mfma_scale_f32_32x32x64_f8f6f4 in the four-stage 256 x 256 kernel (A.T@B), csrc/gnk_gemm_dispatch.h.
 `cutlass_fp8_mm` / `cutlass_scaled_fp8_mm` are the sm120 spellings; they alias the same kernels.
 """
 from __future__ import annotations

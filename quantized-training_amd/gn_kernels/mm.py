@@ -138,9 +138,11 @@ def _tile_scaled_mm_hip(A: Tensor, B: Tensor, scale_A: Tensor, scale_B: Tensor):
     if scale_A.shape[0] == 0 or scale_A.shape[1] == 0 or scale_B.shape[1] == 0:
         raise RuntimeError("gn_kernels::tile_scaled_mm: empty scale tensor")
     QM, QK, QN = M // scale_A.shape[0], K // scale_A.shape[1], N // scale_B.shape[1]
-    if QM < 1 or QN < 1 or QK < 1:
+    # The reference derives the block sizes by floor division and never checks the remainder (triton_mm.py:419,434-436): with M = 100
+    # and 3 scale rows, row 99 would read scale row 3.  The C ABI cannot see the scale extents, so ragged tilings are refused here.
+    if QM < 1 or QN < 1 or QK < 1 or M % scale_A.shape[0] or N % scale_B.shape[1] or K % scale_A.shape[1]:
         raise RuntimeError(f"gn_kernels::tile_scaled_mm: scale shapes {tuple(scale_A.shape)}, {tuple(scale_B.shape)} "
-                           f"do not tile a ({M}, {K}) x ({K}, {N}) product")
+                           f"do not tile a ({M}, {K}) x ({K}, {N}) product evenly")
     C = torch.empty((M, N), device=A.device, dtype=scale_A.dtype)
     L = _cabi.load()
     code = _cabi.DTYPE_CODE

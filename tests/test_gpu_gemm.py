@@ -493,3 +493,13 @@ def test_auto_dispatch_at_benchmark_mid_sizes(S, layout):
     mag8 = (A8.float().abs() * rs.float().abs()) @ (B8.float().abs() * cs.float().abs())
     assert not bool(((out8.float() - want8).abs() > 1.6e-2 * want8.abs() + 5e-5 * mag8 + 1e-5).any())
     _record(f"scaled_fp8_{S}_{layout}", {"failing": _unwidened_failures(out8, want8), "of": S * S})
+
+
+def test_tile_scaled_refuses_ragged_scale_tilings():
+    """M = 100 with 3 scale rows gives QM = 33 and row 99 would index scale row 3 (out of bounds, in the reference too)."""
+    A = torch.zeros(100, 128, dtype=torch.int8, device=DEV)
+    B = torch.zeros(128, 128, dtype=torch.int8, device=DEV)
+    with pytest.raises(RuntimeError, match="evenly"):
+        gn_kernels.scaled_mm(A, B, torch.ones(3, 1, device=DEV), torch.ones(1, 2, device=DEV))
+    ok = gn_kernels.scaled_mm(A, B, torch.ones(4, 1, device=DEV), torch.ones(1, 2, device=DEV))
+    assert ok.shape == (100, 128)

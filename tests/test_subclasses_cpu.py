@@ -226,3 +226,20 @@ def test_ddp_gloo_world2_allreduces_int8_mixed_precision_grads():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(results) == [(0, True), (1, True)]
+
+
+def test_quantize_model_dispatcher_matches_reference_names():
+    """train_utils.quantize_model (reference train_utils.py:35-75): the entry point llm_pretrain.py:122 calls with --quantize / --quantize_kwargs."""
+    from train_utils import quantize_model
+
+    m = nn.Sequential(nn.Linear(16, 8), nn.Linear(8, 4)).to(BF)
+    quantize_model(m, "mixed_precision", grad_weight=False, stochastic_rounding=True)
+    assert isinstance(m[0].weight, MixedPrecisionLinearWeight) and m[1].weight.config == MixedPrecisionConfig(grad_weight=False, stochastic_rounding=True)
+    m = nn.Sequential(nn.Linear(16, 8)).to(BF)
+    quantize_model(m, "int8_quantized_training", activation="int8")
+    assert isinstance(m[0].weight, Int8LinearWeight) and m[0].weight.config == Int8QTConfig(activation="int8")
+    m = nn.Sequential(nn.Linear(16, 8)).to(BF)
+    quantize_model(m, None)
+    assert type(m[0].weight) is nn.Parameter
+    with pytest.raises(AssertionError):
+        quantize_model(m, "nf4")

@@ -1,4 +1,4 @@
-"""Timing ablation of the 256x256 ping-pong GEMM (run on the GPU box): which of LDS-DMA, LDS reads and
+"""[needs an ABLATE build: make -C quantized-training_amd/csrc ABLATE=1 OUT=../gn_kernels/libgnk_hip_ablate.so BUILD=build_ablate, then GNK_LIBRARY=.../libgnk_hip_ablate.so] Timing ablation of the 256x256 ping-pong GEMM (run on the GPU box): which of LDS-DMA, LDS reads and
 MFMA bounds the K loop.  Results of ablated runs are wrong by construction; only times matter."""
 import sys
 from pathlib import Path

@@ -1,4 +1,4 @@
-"""Fixed-overhead and per-phase cost of the 256x256 ping-pong GEMM (GPU box): time vs K at M=N=4096."""
+"""[needs an ABLATE build: make -C quantized-training_amd/csrc ABLATE=1 OUT=../gn_kernels/libgnk_hip_ablate.so BUILD=build_ablate, then GNK_LIBRARY=.../libgnk_hip_ablate.so] Fixed-overhead and per-phase cost of the 256x256 ping-pong GEMM (GPU box): time vs K at M=N=4096."""
 import sys
 from pathlib import Path
 

@@ -1,4 +1,4 @@
-"""Fixed cost of the 8-phase 256x256 kernel (variant 4) at K = 256: kernel durations under rocprofv3 for the ablation flags."""
+"""[needs an ABLATE build: make -C quantized-training_amd/csrc ABLATE=1 OUT=../gn_kernels/libgnk_hip_ablate.so BUILD=build_ablate, then GNK_LIBRARY=.../libgnk_hip_ablate.so] Fixed cost of the 8-phase 256x256 kernel (variant 4) at K = 256: kernel durations under rocprofv3 for the ablation flags."""
 import sys
 from pathlib import Path
 

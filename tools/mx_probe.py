@@ -1,4 +1,4 @@
-"""MXFP4 GEMM and quantize_mx timings (event-timed), FP4 rate against the 10 PFLOP/s dense peak."""
+"""[needs an ABLATE build: make -C quantized-training_amd/csrc ABLATE=1 OUT=../gn_kernels/libgnk_hip_ablate.so BUILD=build_ablate, then GNK_LIBRARY=.../libgnk_hip_ablate.so] MXFP4 GEMM and quantize_mx timings (event-timed), FP4 rate against the 10 PFLOP/s dense peak."""
 import sys
 from pathlib import Path
 

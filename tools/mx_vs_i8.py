@@ -1,4 +1,4 @@
-"""Same bytes, same tile program: int8 4-stage kernel at K = 2048 bytes vs the 256 x 256 MXFP4 kernel at K = 4096 (2048 bytes), random and zero data."""
+"""[needs an ABLATE build: make -C quantized-training_amd/csrc ABLATE=1 OUT=../gn_kernels/libgnk_hip_ablate.so BUILD=build_ablate, then GNK_LIBRARY=.../libgnk_hip_ablate.so] Same bytes, same tile program: int8 4-stage kernel at K = 2048 bytes vs the 256 x 256 MXFP4 kernel at K = 4096 (2048 bytes), random and zero data."""
 import sys
 from pathlib import Path
 

@@ -1,4 +1,4 @@
-"""Row-wise quantize 4096x4096 bf16 under the experiment flags (run under rocprofv3 for kernel times)."""
+"""[needs an ABLATE build: make -C quantized-training_amd/csrc ABLATE=1 OUT=../gn_kernels/libgnk_hip_ablate.so BUILD=build_ablate, then GNK_LIBRARY=.../libgnk_hip_ablate.so] Row-wise quantize 4096x4096 bf16 under the experiment flags (run under rocprofv3 for kernel times)."""
 import sys
 from pathlib import Path
 
