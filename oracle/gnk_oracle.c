@@ -162,7 +162,8 @@ int orc_quantize_int8(const void *x, int x_dtype, int64_t R, int64_t C, int64_t 
             }
             if (v < -128.0f) v = -128.0f;                    /* :25 clip(-128, 127) */
             if (v > 127.0f) v = 127.0f;
-            q[r * sqr + c * sqc] = (int8_t)v;
+            /* NaN quotient (NaN row, Inf / Inf): the reference casts NaN to int8, implementation-defined; this build defines it as 0 */
+            q[r * sqr + c * sqc] = v != v ? (int8_t)0 : (int8_t)v;
         }
         store_float(scale_out, x_dtype, r, scale);           /* :26 scale.to(dtype) */
     }

@@ -174,7 +174,12 @@ __device__ __forceinline__ void gnk_sr_uniform4(unsigned long long seed, unsigne
 }
 
 // stochastic rounding of an already divided value: floor(v + u), clipped (subclasses/int8.py:21,25)
-__device__ __forceinline__ int gnk_sr_clip_i8(float v, float u) { return (int)fminf(fmaxf(floorf(v + u), -128.0f), 127.0f); }
+// NaN quotients (NaN / x, x / NaN, Inf / Inf) become 0: the reference casts NaN to int8 there, which is implementation-defined (0 on
+// x86 and on NVIDIA's saturating conversion); without the select fmaxf would turn them into -128.
+__device__ __forceinline__ int gnk_sr_clip_i8(float v, float u) {
+    const int r = (int)fminf(fmaxf(floorf(v + u), -128.0f), 127.0f);
+    return v == v ? r : 0;
+}
 
 // One quantization step of subclasses/int8.py:18-25 given the divisor max(scale, eps).
 template <bool SR>
@@ -183,8 +188,8 @@ __device__ __forceinline__ int gnk_quant_one(float x, float div, unsigned long l
     float v = x / div;                     // true IEEE division (no fast-math in this build)
     if constexpr (SR) v = floorf(v + gnk_sr_uniform(seed, offset, idx));
     else v = rintf(v);                     // v_rndne_f32: round half to even
-    v = fminf(fmaxf(v, -128.0f), 127.0f);
-    return (int)v;
+    const int r = (int)fminf(fmaxf(v, -128.0f), 127.0f);
+    return v == v ? r : 0;                 // NaN quotient -> 0 (see gnk_sr_clip_i8)
 }
 
 // Division by a divisor that many elements share.  A true fp32 division is ~10 VALU instructions
@@ -209,4 +214,34 @@ struct GnkDivisor {
     }
 };
 
-__device__ __forceinline__ int gnk_rne_clip_i8(float v) { return (int)fminf(fmaxf(rintf(v), -128.0f), 127.0f); }
+__device__ __forceinline__ int gnk_rne_clip_i8(float v) { return (int)fminf(fmaxf(rintf(v), -128.0f), 127.0f); }   // finite v (GnkDivisor fast path)
+// the true-division path also sees NaN / Inf rows: NaN quotient -> 0 (see gnk_sr_clip_i8)
+__device__ __forceinline__ int gnk_rne_clip_i8_any(float v) { return v == v ? gnk_rne_clip_i8(v) : 0; }
+// max(scale, eps) as torch.clamp_min computes it: a NaN scale stays NaN (fmaxf alone would return eps and hide the NaN row)
+__device__ __forceinline__ float gnk_clamp_min_nan(float s, float eps) { return s == s ? fmaxf(s, eps) : s; }
+
+// Running |x| maximum that PROPAGATES NaN, as the reference's abs().amax() does (subclasses/int8.py:17): kept as bit patterns, which order
+// like the magnitudes for every non-negative float, Inf and NaN included (NaN patterns exceed Inf's).  16-bit inputs: two packed patterns
+// per word (v_and + v_pk_max_u16 per TWO elements, cheaper than unpack + v_max_f32); fp32: one pattern per word.
+typedef unsigned short gnk_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned gnk_pk_max_u16(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(gnk_us2, a), __builtin_bit_cast(gnk_us2, b)));
+}
+template <int DT> struct GnkAbsMax {
+    unsigned m = 0u;
+    __device__ __forceinline__ void add_word(unsigned w) {      // one dword of the input: 2 x 16-bit elements or 1 x fp32
+        if constexpr (DT == GNK_F32) { const unsigned a = w & 0x7fffffffu; m = a > m ? a : m; }
+        else m = gnk_pk_max_u16(m, w & 0x7fff7fffu);
+    }
+    __device__ __forceinline__ void add16(const v4i &raw) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) add_word((unsigned)raw[j]);
+    }
+    // this lane's maximum as an fp32 bit pattern (order-preserving, so lanes / waves can go on reducing with integer max)
+    __device__ __forceinline__ unsigned bits() const {
+        if constexpr (DT == GNK_F32) return m;
+        const unsigned lo = m & 0xffffu, hi = m >> 16, h = lo > hi ? lo : hi;
+        if constexpr (DT == GNK_BF16) return h << 16;
+        else return __float_as_uint(gnk_f16_to_f32((unsigned short)h));
+    }
+};

@@ -41,9 +41,13 @@ template <int DT> __device__ __forceinline__ void unpack16(const v4i &raw, float
     }
 }
 
-__device__ __forceinline__ float wave_max(float v) {
+// wave-wide maximum of non-negative fp32 BIT PATTERNS (integer max: NaN and Inf keep their order, see GnkAbsMax)
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)v, off, 64);
+        v = o > v ? o : v;
+    }
     return v;
 }
 
@@ -82,7 +86,7 @@ __device__ __forceinline__ void quant_chunk(const v4i &raw, const GnkDivisor &dv
             for (int j = 0; j < VEC; ++j) qi[j] = gnk_rne_clip_i8(dv.quot(f[j]));
         } else {
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) qi[j] = gnk_rne_clip_i8(f[j] / dv.d);
+            for (int j = 0; j < VEC; ++j) qi[j] = gnk_rne_clip_i8_any(f[j] / dv.d);
         }
     }
     if constexpr (VEC == 8) {
@@ -127,18 +131,13 @@ quant_rowwise_kernel(const char *__restrict__ x, int8_t *__restrict__ q, void *_
                 if (ch < nchunks) nxt[i] = *(const v4i *)(x + rn * sxr_bytes + (int64_t)ch * 16);
             }
         }
-        float amax = 0.0f;
+        GnkAbsMax<DT> am;
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            float f[VEC];
-            unpack16<DT>(raw[i], f);
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) amax = fmaxf(amax, fabsf(f[j]));
-        }
-        amax = wave_max(amax);
+        for (int i = 0; i < NCH; ++i) am.add16(raw[i]);
+        const float amax = __uint_as_float(wave_umax(am.bits()));
         const float s = amax / 127.0f;
         GnkDivisor dv;
-        dv.set(fmaxf(s, eps));
+        dv.set(gnk_clamp_min_nan(s, eps));
         const bool fast = dv.ok();
         if (lane == 0) gnk_store_scalar_rt(scale, DT, r, s);
 
@@ -161,24 +160,20 @@ quant_rowwise_long_kernel(const char *__restrict__ x, int8_t *__restrict__ q, vo
                           int64_t R, int64_t C, int64_t sxr_bytes, int64_t sqr, float eps,
                           unsigned long long seed, unsigned long long offset) {
     constexpr int VEC = ElemTraits<DT>::VEC;
-    __shared__ float red[4];
+    __shared__ unsigned red[4];
     const int64_t r = blockIdx.x;
     const int64_t nchunks = C / VEC;
     const char *xrow = x + r * sxr_bytes;
-    float amax = 0.0f;
-    for (int64_t ch = threadIdx.x; ch < nchunks; ch += 256) {
-        float f[VEC];
-        unpack16<DT>(*(const v4i *)(xrow + ch * 16), f);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) amax = fmaxf(amax, fabsf(f[j]));
-    }
-    amax = wave_max(amax);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+    GnkAbsMax<DT> am;
+    for (int64_t ch = threadIdx.x; ch < nchunks; ch += 256) am.add16(*(const v4i *)(xrow + ch * 16));
+    const unsigned wmax = wave_umax(am.bits());
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = wmax;
     __syncthreads();
-    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const unsigned m01 = red[0] > red[1] ? red[0] : red[1], m23 = red[2] > red[3] ? red[2] : red[3];
+    const float amax = __uint_as_float(m01 > m23 ? m01 : m23);
     const float s = amax / 127.0f;
     GnkDivisor dv;
-    dv.set(fmaxf(s, eps));
+    dv.set(gnk_clamp_min_nan(s, eps));
     const bool fast = dv.ok();
     if (threadIdx.x == 0) gnk_store_scalar_rt(scale, DT, r, s);
     int8_t *qrow = q + r * sqr;
@@ -200,11 +195,6 @@ quant_rowwise_long_kernel(const char *__restrict__ x, int8_t *__restrict__ q, vo
 //     slower): the block's 8 waves merge through LDS (ds_max_u32 per column) and write ONE partial
 //     row; a second, tiny kernel reduces the <= 2 * CUs partial rows to fp32 column maxima.
 // ------------------------------------------------------------------------------------------
-typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
-    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
-}
 
 template <int DT, int NCH, bool SR, bool NT>
 __global__ void __launch_bounds__(512)
@@ -258,23 +248,20 @@ quant_rowwise_colmax_kernel(const char *__restrict__ x, int8_t *__restrict__ q, 
                 if (ch < nchunks) raw[i] = *(const v4i *)(x + r * sxr_bytes + (int64_t)ch * 16);
             }
         }
-        float amax = 0.0f;
+        GnkAbsMax<DT> am;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            float f[VEC];
-            unpack16<DT>(raw[i], f);
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) amax = fmaxf(amax, fabsf(f[j]));
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if constexpr (DT == GNK_F32) cm[i][j] = __float_as_uint(fmaxf(__uint_as_float(cm[i][j]), fabsf(f[j])));
-                else cm[i][j] = pk_max_u16(cm[i][j], (unsigned)raw[i][j] & 0x7fff7fffu);
+                const unsigned a = (unsigned)raw[i][j] & (DT == GNK_F32 ? 0x7fffffffu : 0x7fff7fffu);   // |x| bit patterns (1 or 2 per word)
+                if constexpr (DT == GNK_F32) { cm[i][j] = a > cm[i][j] ? a : cm[i][j]; am.m = a > am.m ? a : am.m; }
+                else { cm[i][j] = gnk_pk_max_u16(cm[i][j], a); am.m = gnk_pk_max_u16(am.m, a); }
             }
         }
-        amax = wave_max(amax);
+        const float amax = __uint_as_float(wave_umax(am.bits()));
         const float s = amax / 127.0f;
         GnkDivisor dv;
-        dv.set(fmaxf(s, eps));
+        dv.set(gnk_clamp_min_nan(s, eps));
         const bool fast = dv.ok();
         if (lane == 0) gnk_store_scalar_rt(scale, DT, r, s);
 
@@ -354,13 +341,11 @@ __global__ void __launch_bounds__(256)
 col_absmax_kernel(const char *__restrict__ x, unsigned *__restrict__ amax_ws, int64_t P, int64_t Q,
                   int64_t ld_bytes) {
     constexpr int VEC = ElemTraits<DT>::VEC;
-    __shared__ float red[8][32 * VEC + 1];
+    __shared__ unsigned red[8][32 * VEC + 1];             // fp32 bit patterns of |x| maxima (integer order: NaN > Inf > finite, GnkAbsMax)
     const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int64_t col0 = ((int64_t)blockIdx.x * 32 + cl) * VEC;
     const int64_t row0 = (int64_t)blockIdx.y * COL_PB;
-    float m[VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) m[j] = 0.0f;
+    unsigned mw[4] = {0u, 0u, 0u, 0u};                     // per input dword: 2 packed 16-bit patterns, or 1 fp32 pattern
     if (col0 < Q) {
         constexpr int NIT = COL_PB / 8;
         v4i raw[NIT];
@@ -371,23 +356,29 @@ col_absmax_kernel(const char *__restrict__ x, unsigned *__restrict__ amax_ws, in
             if (row < P) raw[i] = *(const v4i *)(x + row * ld_bytes + col0 * (16 / VEC));
         }
 #pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            float f[VEC];
-            unpack16<DT>(raw[i], f);
+        for (int i = 0; i < NIT; ++i)
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) m[j] = fmaxf(m[j], fabsf(f[j]));
-        }
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (DT == GNK_F32) { const unsigned a = (unsigned)raw[i][j] & 0x7fffffffu; mw[j] = a > mw[j] ? a : mw[j]; }
+                else mw[j] = gnk_pk_max_u16(mw[j], (unsigned)raw[i][j] & 0x7fff7fffu);
+            }
     }
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) red[rl][cl * VEC + j] = m[j];
+    for (int j = 0; j < 4; ++j) {
+        if constexpr (DT == GNK_F32) red[rl][cl * VEC + j] = mw[j];
+        else if constexpr (DT == GNK_BF16) { red[rl][cl * VEC + 2 * j] = (mw[j] & 0xffffu) << 16; red[rl][cl * VEC + 2 * j + 1] = mw[j] & 0xffff0000u; }
+        else {
+            red[rl][cl * VEC + 2 * j] = __float_as_uint(gnk_f16_to_f32((unsigned short)(mw[j] & 0xffffu)));
+            red[rl][cl * VEC + 2 * j + 1] = __float_as_uint(gnk_f16_to_f32((unsigned short)(mw[j] >> 16)));
+        }
+    }
     __syncthreads();
     for (int c = threadIdx.x; c < 32 * VEC; c += 256) {
-        float v = red[0][c];
+        unsigned v = red[0][c];
 #pragma unroll
-        for (int i = 1; i < 8; ++i) v = fmaxf(v, red[i][c]);
+        for (int i = 1; i < 8; ++i) v = red[i][c] > v ? red[i][c] : v;
         const int64_t col = (int64_t)blockIdx.x * 32 * VEC + c;
-        // non-negative floats order like their bit patterns
-        if (col < Q && v > 0.0f) atomicMax(amax_ws + col, __float_as_uint(v));
+        if (col < Q && v) atomicMax(amax_ws + col, v);
     }
 }
 
@@ -406,7 +397,7 @@ col_quant_kernel(const char *__restrict__ x, int8_t *__restrict__ q, void *__res
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         const float s = __uint_as_float(amax_ws[col0 + j]) / 127.0f;
-        dv[j].set(fmaxf(s, eps));
+        dv[j].set(gnk_clamp_min_nan(s, eps));
         fast = fast && dv[j].ok();
         if (blockIdx.y == 0 && rl == 0) gnk_store_scalar_rt(scale, DT, col0 + j, s);
     }
@@ -469,7 +460,7 @@ col_quant_kernel(const char *__restrict__ x, int8_t *__restrict__ q, void *__res
                     for (int j = 0; j < VEC; ++j) qi[j] = gnk_rne_clip_i8(dv[j].quot(f[j]));
                 } else {
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) qi[j] = gnk_rne_clip_i8(f[j] / dv[j].d);
+                    for (int j = 0; j < VEC; ++j) qi[j] = gnk_rne_clip_i8_any(f[j] / dv[j].d);
                 }
                 store_row(row, qi);
             }
@@ -485,17 +476,21 @@ __global__ void __launch_bounds__(256)
 quant_generic_kernel(const void *__restrict__ x, int dt, int8_t *__restrict__ q, void *__restrict__ scale,
                      int64_t R, int64_t C, int64_t sxr, int64_t sxc, int64_t sqr, int64_t sqc, float eps,
                      unsigned long long seed, unsigned long long offset) {
-    __shared__ float red[4];
+    __shared__ unsigned red[4];
     for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
-        float amax = 0.0f;
-        for (int64_t c = threadIdx.x; c < C; c += 256) amax = fmaxf(amax, fabsf(gnk_load_scalar_rt(x, dt, r * sxr + c * sxc)));
-        amax = wave_max(amax);
+        unsigned mb = 0u;                                  // |x| maximum as an fp32 bit pattern (NaN-propagating, GnkAbsMax)
+        for (int64_t c = threadIdx.x; c < C; c += 256) {
+            const unsigned a = __float_as_uint(gnk_load_scalar_rt(x, dt, r * sxr + c * sxc)) & 0x7fffffffu;
+            mb = a > mb ? a : mb;
+        }
+        mb = wave_umax(mb);
         __syncthreads();
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mb;
         __syncthreads();
-        amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const unsigned m01 = red[0] > red[1] ? red[0] : red[1], m23 = red[2] > red[3] ? red[2] : red[3];
+        const float amax = __uint_as_float(m01 > m23 ? m01 : m23);
         const float s = amax / 127.0f;
-        const float div = fmaxf(s, eps);
+        const float div = gnk_clamp_min_nan(s, eps);
         if (threadIdx.x == 0) gnk_store_scalar_rt(scale, dt, r, s);
         for (int64_t c = threadIdx.x; c < C; c += 256)
             q[r * sqr + c * sqc] = (int8_t)gnk_quant_one<SR>(gnk_load_scalar_rt(x, dt, r * sxr + c * sxc), div, seed, offset,

@@ -227,3 +227,36 @@ def test_full_size_fused_pair_32768x2048():
     q0, s0 = qmod.quantize_int8_colwise_given(x, cm)
     q0r, s0r = quantize_int8(x, dim=0)
     assert torch.equal(q0, q0r) and bits_equal(s0, s0r)
+
+
+@pytest.mark.parametrize("name", ["bf16", "f16", "f32"])
+def test_nonfinite_inputs_surface_like_the_reference(name):
+    """fmaxf-based absmax dropped NaN and quantized NaN rows with a finite scale.  g9 (reference on the CPU): NaN -> NaN scale,
+    Inf -> Inf scale and zeros; every kernel family (row-wise, strided two-pass, fused pair, long rows, generic) against it."""
+    g = load("g9_quantize_nonfinite.npz")
+    dt = FLOAT_DTYPES[name]
+    x = t_from_bits(g[f"x_{name}"], dt).to(DEV)
+
+    def check(q, s, dim):
+        want_s = t_from_bits(g[f"s_dim{dim}_{name}"], dt).float()
+        got = s.float().cpu().view(want_s.shape)
+        assert torch.equal(torch.isnan(got), torch.isnan(want_s))
+        assert torch.equal(got[~torch.isnan(want_s)], want_s[~torch.isnan(want_s)])
+        undef = torch.from_numpy(g[f"undef_dim{dim}_{name}"])
+        qc = q.cpu()
+        assert torch.equal(qc[~undef], torch.from_numpy(g[f"q_dim{dim}_{name}"])[~undef])
+        assert int(qc[undef].abs().max()) == 0
+
+    check(*quantize_int8(x, dim=1), 1)                       # row-wise register-resident kernel
+    check(*quantize_int8(x, dim=0), 0)                       # strided reduction (absmax pass + quantize pass)
+    q, s, cm = qmod.quantize_int8_rowwise_colmax(x)          # fused pair
+    check(q, s, 1)
+    check(*qmod.quantize_int8_colwise_given(x, cm), 0)
+    xo = torch.zeros(24, 520, device=DEV, dtype=dt)[:, 3:515]   # unaligned base: generic kernel
+    xo.copy_(x)
+    check(*quantize_int8(xo, dim=1), 1)
+    check(*quantize_int8(xo, dim=0), 0)
+    # long rows (two-pass row kernel): tile the 512 columns to 16896 > 16384
+    xl = x.repeat(1, 33)
+    ql, sl = quantize_int8(xl, dim=1)
+    check(ql[:, :512], sl, 1)

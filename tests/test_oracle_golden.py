@@ -162,3 +162,25 @@ def test_cutlass_epilogue_order_differs_only_in_last_ulp():
     a = oracle.scaled_mm(A, B, rs, cs, out_dtype=torch.float32, order=0)
     b = oracle.scaled_mm(A, B, rs, cs, out_dtype=torch.float32, order=1)
     torch.testing.assert_close(a, b, rtol=3e-7, atol=0)
+
+
+@pytest.mark.parametrize("name", ["bf16", "f16", "f32"])
+@pytest.mark.parametrize("dim", [1, 0])
+def test_quantize_nonfinite_golden(name, dim):
+    """g9 (tools/gen_golden_nonfinite.py, from the reference on the CPU): a NaN makes its row's scale NaN, an Inf makes it Inf and every
+    finite element 0.  Elements whose quotient is NaN are a cast of NaN in the reference (implementation-defined): compared outside the
+    fixture's mask only; there this build writes 0."""
+    import oracle
+    from tests._util import FLOAT_DTYPES
+
+    g = load("g9_quantize_nonfinite.npz")
+    dt = FLOAT_DTYPES[name]
+    x = t_from_bits(g[f"x_{name}"], dt)
+    q, s = oracle.quantize_int8(x, dim=dim)
+    want_s = t_from_bits(g[f"s_dim{dim}_{name}"], dt)
+    assert torch.equal(torch.isnan(s.float()), torch.isnan(want_s.float()))
+    fin = ~torch.isnan(want_s.float())
+    assert torch.equal(s.float()[fin], want_s.float()[fin])
+    undef = torch.from_numpy(g[f"undef_dim{dim}_{name}"])
+    assert torch.equal(q[~undef], torch.from_numpy(g[f"q_dim{dim}_{name}"])[~undef])
+    assert int(q[undef].abs().max()) == 0
