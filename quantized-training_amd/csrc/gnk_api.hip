@@ -222,20 +222,23 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
         const int64_t amax = ((c.M - 1) / c.QM) * c.ssam + (c.K / c.QK) * c.ssak, bmax = (c.K / c.QK) * c.ssbk + ((c.N - 1) / c.QN) * c.ssbn;
         tile_ok = (c.QK % GNK_BK == 0 || c.QK == 64 || c.QK == 32) && c.QK / GNK_BK < (1 << 20) && c.K % c.QK == 0 && c.QN % 4 == 0 && c.N % 4 == 0 && c.ssam >= 0 && c.ssak >= 0 && c.ssbk >= 0 && c.ssbn >= 0 && amax < (1LL << 31) && bmax < (1LL << 31);
     }
-    const bool ok_128 = fast_layout && c.K >= GNK_BK && c.K % GNK_BK == 0 && tile_ok;
+    // the 128 x 128 kernel masks a K tail itself (any K; plain and row/col epilogues); the tile-scaled epilogue needs whole 128-k steps
+    const bool ok_128 = fast_layout && c.K >= 1 && (c.K % GNK_BK == 0 || c.epi != EPI_TILE) && tile_ok;
+    const bool whole_steps = c.K >= GNK_BK && c.K % GNK_BK == 0;
     if ((variant == GNK_VARIANT_256_SIMPLE && op != OP_I8) || ((variant == GNK_VARIANT_256_SIMPLE || variant == GNK_VARIANT_256_PP8) && c.epi == EPI_TILE)) variant = GNK_VARIANT_256;
     if (variant == GNK_VARIANT_256 && c.epi == EPI_TILE) variant = GNK_VARIANT_128;
     int splits = 1;
     if (variant < 0 || variant > GNK_VARIANT_LAST) {
-        const bool can_split = c.ws && op == OP_I8 && c.epi == EPI_ROWCOL && ok_128 && c.N % 4 == 0 && ((uintptr_t)c.C & 15) == 0 && ((uintptr_t)c.ws & 15) == 0;
+        const bool can_split = c.ws && op == OP_I8 && c.epi == EPI_ROWCOL && ok_128 && whole_steps && c.N % 4 == 0 && ((uintptr_t)c.C & 15) == 0 && ((uintptr_t)c.ws & 15) == 0;
         const GemmPlan plan = plan_gemm(c.M, c.N, c.K, ok_pp2, ok_128, can_split);
         variant = plan.variant;
         if (plan.splits > 1 && c.ws_bytes >= (int64_t)plan.splits * c.M * c.N * 4) splits = plan.splits;
         // A K-major (A@B.T, A@B): the 8-phase kernel.  Measured at 4096^3 against the 4-stage one (tools/cmp_variants.py, round 2): int8
         // A@B.T 54.0 vs 59.4 us, A@B 56.2 vs 57.5; fp8 (one 16x16x128 MFMA per tile and step instead of two 32x32x64) A@B.T 52.2 vs 59.4,
         // A@B 54.1 vs 55.7.  A M-major (A.T@B) stays on the 4-stage kernel (fp8 55.3 vs 57.9, int8 level).
-        if (variant == GNK_VARIANT_256 && la.kmajor && ok_128) variant = GNK_VARIANT_256_PP8;
-    } else if (variant != GNK_VARIANT_GENERIC && !(variant == GNK_VARIANT_256 ? ok_pp2 : ok_128)) {
+        if (variant == GNK_VARIANT_256 && la.kmajor && ok_128 && whole_steps) variant = GNK_VARIANT_256_PP8;
+    } else if (variant != GNK_VARIANT_GENERIC &&
+               !(variant == GNK_VARIANT_256 ? ok_pp2 : variant == GNK_VARIANT_128 ? ok_128 : (ok_128 && whole_steps))) {
         return gnk_fail(GNK_ERR_UNSUPPORTED, "%s: forced fast variant %d cannot take these strides / sizes", name, variant);
     }
 

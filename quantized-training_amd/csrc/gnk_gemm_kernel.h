@@ -130,7 +130,50 @@ struct Stager {
         }
         base += step;
     }
+
+    // The LAST K-step when K % 128 != 0: only k < kvalid of the tile exist.  Pieces that lie wholly beyond them are fetched from the
+    // tile's first chunk / k-row instead (valid memory; a K-major chunk that straddles kvalid stays inside the row pitch, which the
+    // host requires to be >= K rounded up to 16): what they bring is garbage that zero_tail() clears before any fragment is read.
+    __device__ __forceinline__ void issue_tail(char *tile, int64_t ld, int64_t r0, int64_t extent, int wave, int lane, int kvalid) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int pc = i * NW + wave;
+            const int p = pc * 64 + lane;
+            unsigned o = off[i];
+            if constexpr (KMAJOR) {
+                int r, c;
+                gnk_kmaj_stage_src(p, r, c);
+                if (16 * c >= kvalid) o -= 16u * (unsigned)c;                       // chunk 0 of the same row
+            } else {
+                int k, c;
+                gnk_mnmaj_stage_src<ROWS>(p, k, c);
+                if (k >= kvalid) o -= (unsigned)((int64_t)k * ld);                  // k-row 0, same columns
+            }
+            __builtin_amdgcn_global_load_lds((const GNK_GLOBAL void *)(base + o), (GNK_LDS void *)(tile + pc * 1024), 16, 0, 0);
+        }
+        base += step;
+    }
 };
+
+// Clear k >= kvalid of a staged tile (the last K-step of a K that is not a multiple of 128): zero bytes are 0 in int8 and +0 in both
+// fp8 formats, so the tail adds nothing to any dot product.  Called by every thread after the tile has landed (vmcnt(0) + barrier);
+// the caller puts a barrier behind it.
+template <bool KMAJOR, int ROWS, int NT>
+__device__ __forceinline__ void zero_tail(char *tile, int kvalid) {
+    if constexpr (KMAJOR) {
+        const int d0 = kvalid >> 2, nd = 32 - d0;                                    // dwords d0 .. 31 of every row hold k >= 4 d0
+        for (int e = threadIdx.x; e < ROWS * nd; e += NT) {
+            const int r = e / nd, d = d0 + e % nd;
+            GNK_LDS unsigned *w = (GNK_LDS unsigned *)(GNK_LDS char *)(tile + gnk_kmaj_offset(r, d >> 2) + 4 * (d & 3));
+            const int keep = kvalid - 4 * d;                                         // bytes of this dword that are real (<= 3 here, or <= 0)
+            *w = keep > 0 ? (*w & ((1u << (8 * keep)) - 1u)) : 0u;
+        }
+    } else {
+        // k-rows are ROWS contiguous bytes (the swizzle permutes chunks inside a row): one linear fill
+        for (int o = kvalid * ROWS + 16 * (int)threadIdx.x; o < 128 * ROWS; o += 16 * NT)
+            *(GNK_LDS v4i *)(GNK_LDS char *)(tile + o) = (v4i){0, 0, 0, 0};
+    }
+}
 
 // ------------------------------------------------------------------------------ fragment reads
 template <bool KMAJOR, int ROWS>
@@ -626,7 +669,8 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
     // and as many in flight for the next one spilled registers.
     constexpr bool PANEL_B = NB > 1;
     constexpr int TS_PEB = PANEL_B ? Cfg::BN * TS_STEPS / Cfg::NT : 1;
-    const int nk = (int)(p.K / GNK_BK);
+    const int nk = (int)((p.K + GNK_BK - 1) / GNK_BK);          // the last step may be partial (plain / row-col epilogues; host-checked)
+    const int ktail = (int)(p.K % GNK_BK);                        // k elements of that partial step (0: none)
     const int G = MULTI && p.kgroup > 1 ? p.kgroup : 1;                             // K-steps per scale block (QK = G * 128)
     const int nks = (nk * NB + G - 1) / G;                                          // scale steps along K
     const int psteps = PS * G;                                                      // K-steps covered by one panel
@@ -686,8 +730,13 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
     }
 
     if (nk > 0) {
-        sa.issue(As0, wave);
-        sb.issue(Bs0, wave);
+        if (nk == 1 && ktail) {
+            sa.issue_tail(As0, p.lda, m0, p.M, wave, lane, ktail);
+            sb.issue_tail(Bs0, p.ldb, n0, p.N, wave, lane, ktail);
+        } else {
+            sa.issue(As0, wave);
+            sb.issue(Bs0, wave);
+        }
     }
     // scale bookkeeping as running counters (wave-uniform; divisions by the run-time G cost ~5 % of the tile-scaled fp8 kernel):
     // c_gph = t % G, c_u = t / G (scale step), c_tk = t % psteps, c_tsi = c_tk / G, c_pn = t / psteps (panel number)
@@ -714,9 +763,21 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
         }
 
         const int cur = t & 1;
+        if constexpr (Cfg::EPI != EPI_TILE) {
+            if (ktail && t + 1 == nk) {      // partial last step: clear k >= ktail of both tiles (wave-uniform branch, once per kernel)
+                zero_tail<Cfg::A_KMAJOR, Cfg::BM, Cfg::NT>(As0 + cur * Cfg::A_BYTES, ktail);
+                zero_tail<Cfg::B_KMAJOR, Cfg::BN, Cfg::NT>(Bs0 + cur * Cfg::B_BYTES, ktail);
+                __syncthreads();
+            }
+        }
         if (t + 1 < nk) {
-            sa.issue(As0 + (cur ^ 1) * Cfg::A_BYTES, wave);
-            sb.issue(Bs0 + (cur ^ 1) * Cfg::B_BYTES, wave);
+            if (Cfg::EPI != EPI_TILE && ktail && t + 2 == nk) {
+                sa.issue_tail(As0 + (cur ^ 1) * Cfg::A_BYTES, p.lda, m0, p.M, wave, lane, ktail);
+                sb.issue_tail(Bs0 + (cur ^ 1) * Cfg::B_BYTES, p.ldb, n0, p.N, wave, lane, ktail);
+            } else {
+                sa.issue(As0 + (cur ^ 1) * Cfg::A_BYTES, wave);
+                sb.issue(Bs0 + (cur ^ 1) * Cfg::B_BYTES, wave);
+            }
         }
         if constexpr (Cfg::EPI != EPI_TILE) {
             compute_step<Cfg, false>(As0 + cur * Cfg::A_BYTES, Bs0 + cur * Cfg::B_BYTES, acc, wm, wn, lane);

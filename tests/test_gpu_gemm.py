@@ -197,7 +197,7 @@ def test_tile_scaled_small_k_blocks_fp8(fmts, qk):
 @pytest.mark.parametrize("fmts", [("e4m3", "e4m3"), ("e5m2", "e4m3"), ("e4m3", "e5m2"), ("e5m2", "e5m2")])
 @pytest.mark.parametrize("layout", list(LAYOUTS))
 def test_fp8_paths_vs_oracle(fmts, layout, variant):
-    if variant in ("tile256simple", "tile256pp8"):
+    if variant == "tile256simple":
         pytest.skip("int8-only variant")
     M, N, K = 256, 384, 512
     g = torch.Generator().manual_seed(11)
@@ -503,3 +503,47 @@ def test_tile_scaled_refuses_ragged_scale_tilings():
         gn_kernels.scaled_mm(A, B, torch.ones(3, 1, device=DEV), torch.ones(1, 2, device=DEV))
     ok = gn_kernels.scaled_mm(A, B, torch.ones(4, 1, device=DEV), torch.ones(1, 2, device=DEV))
     assert ok.shape == (100, 128)
+
+
+# ------------------------------------------------------------------------------- K tails on the MFMA kernel
+def _padded(x, column_major, pad_to=16):
+    """x on the device in the given layout inside a buffer whose leading dimension is a multiple of 16 bytes (what the MFMA path needs);
+    the padding holds 0x7f garbage (a NaN in e4m3) that must never reach a result."""
+    src = x.T if column_major else x
+    rows, cols = src.shape
+    ld = (cols + pad_to - 1) // pad_to * pad_to + pad_to
+    buf = torch.full((rows + 1, ld), 0x7f, dtype=torch.uint8, device=DEV).view(x.dtype)
+    buf[:rows, :cols] = src.to(DEV)
+    v = buf[:rows, :cols]
+    return v.T if column_major else v
+
+
+@pytest.mark.parametrize("K", [1, 16, 48, 100, 127, 130, 200, 333, 1000, 16448])
+@pytest.mark.parametrize("layout", list(LAYOUTS))
+def test_k_tails_run_on_the_mfma_kernel_bit_exact(K, layout):
+    """The reference takes any even K (triton_mm.py:140,404; SURVEY 7.2 names ViT's K = 16448): the 128 x 128 MFMA kernel masks the last,
+    partial K-step in LDS.  Forced onto that kernel (the call fails if the shape were not eligible), int8 bit-exact against the oracle,
+    fp8 within the stated tolerance; the garbage beside the operands (row padding, rows beyond K) must not leak."""
+    M, N = (144, 112) if K < 10000 else (128, 128)
+    g = torch.Generator().manual_seed(K)
+    acm, bcm = LAYOUTS[layout]
+    A = torch.randint(-128, 128, (M, K), dtype=torch.int8, generator=g)
+    B = torch.randint(-128, 128, (K, N), dtype=torch.int8, generator=g)
+    rs = torch.randn(M, 1, generator=g).div(128).bfloat16()
+    cs = torch.randn(1, N, generator=g).div(128).bfloat16()
+    Ad, Bd = _padded(A, acm), _padded(B, bcm)
+    L = _cabi.load()
+    L.gnk_set_gemm_variant(VARIANTS["tile128"])
+    try:
+        assert torch.equal(gn_kernels.int8_mm(Ad, Bd).cpu(), oracle.int8_mm(A, B))
+        assert bits_equal(gn_kernels.scaled_mm(Ad, Bd, rs.to(DEV), cs.to(DEV)), oracle.scaled_mm(A, B, rs, cs))
+        if K <= 1000:
+            A8 = torch.randn(M, K, generator=g).to(torch.float8_e4m3fn)
+            B8 = torch.randn(K, N, generator=g).to(torch.float8_e5m2)
+            got = gn_kernels.scaled_mm(_padded(A8, acm), _padded(B8, bcm), rs.to(DEV), cs.to(DEV))
+            assert_fp8_close(got, oracle.scaled_mm(A8, B8, rs, cs), fp8_mag(A8, B8, rs, cs))
+    finally:
+        L.gnk_set_gemm_variant(-1)
+    # the heuristic must take an MFMA kernel too (same bits), not the generic fallback: compare, and for the big K time-box it
+    out = gn_kernels.scaled_mm(Ad, Bd, rs.to(DEV), cs.to(DEV))
+    assert bits_equal(out, oracle.scaled_mm(A, B, rs, cs))
