@@ -123,3 +123,19 @@ def test_mx_errors_surface_as_exceptions():
     s = torch.zeros(4, 1, dtype=torch.uint8, device=DEV).view(mx.E8M0)
     with pytest.raises(RuntimeError):
         mx.mxfp4_mm(A, A.T.contiguous().T[:, :4] if False else torch.zeros(4, 24, dtype=torch.uint8, device=DEV).view(mx.FP4).T, s, s)
+
+
+@pytest.mark.parametrize("tag", ["mfma_ocp", "mfma_nv", "generic_ocp", "generic_nv"])
+def test_mxfp4_mm_against_the_reference_derived_golden(tag):
+    """PINNED through the reference's own CPU functions (g10, tools/gen_golden_mxfp4_mm.py): operands = reference quantize_mx output,
+    expectation = exact product of the reference's dequantize_mxfp4 values (+ bias).  STATED TOLERANCE: |got - want| <= 1.6e-2 |want|
+    (bf16 assert_close default, benchmark_mm.py:128-145) + 2e-5 sum|a b| (sub-fp32 accumulation inside the scaled MFMA) + 1e-5."""
+    g = load("g10_mxfp4_mm.npz")
+    A, B = torch.from_numpy(g[f"A_{tag}"]).to(DEV).view(mx.FP4), torch.from_numpy(g[f"B_{tag}"]).to(DEV).view(mx.FP4)
+    sA, sB = torch.from_numpy(g[f"sA_{tag}"]).to(DEV).view(mx.E8M0), torch.from_numpy(g[f"sB_{tag}"]).to(DEV).view(mx.E8M0)
+    bias = torch.from_numpy(g[f"bias_{tag.split('_')[0]}"]).view(torch.bfloat16)
+    for b in (None, bias):
+        got = mx.mxfp4_mm(A, B.T, sA, sB, b.to(DEV) if b is not None else None).float().cpu().numpy().astype(np.float64)
+        want = g[f"C_{tag}"] + (b.float().numpy().astype(np.float64)[None, :] if b is not None else 0.0)
+        bound = 1.6e-2 * np.abs(want) + 2e-5 * g[f"mag_{tag}"] + 1e-5
+        assert (np.abs(got - want) <= bound).all(), f"worst excess {(np.abs(got - want) - bound).max():.3e}"

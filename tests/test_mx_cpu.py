@@ -56,3 +56,15 @@ def test_mx_ops_validate_like_the_reference():
         mx.quantize_mx(torch.zeros(4, 32), mx.FP4, "bogus")
     out = torch.ops.gn_kernels.mxfp4_mm(A.to("meta"), A.to("meta").T.contiguous().T, torch.empty(4, 1, device="meta", dtype=mx.E8M0), torch.empty(16, 1, device="meta", dtype=mx.E8M0), None)
     assert out.shape == (4, 16) and out.dtype is torch.bfloat16
+
+
+@pytest.mark.parametrize("tag", ["mfma_ocp", "mfma_nv", "generic_ocp", "generic_nv"])
+def test_mxfp4_mm_oracle_matches_the_reference_derived_product(tag):
+    """g10 (tools/gen_golden_mxfp4_mm.py): operands from the reference's quantize_mx, expectation = the reference's dequantize_mxfp4 of
+    both, multiplied exactly.  The numpy oracle must reproduce it to the last bit (all factors are dyadic rationals: fp64 is exact)."""
+    from oracle import mx_ref
+
+    g = load("g10_mxfp4_mm.npz")
+    want = g[f"C_{tag}"]
+    got = mx_ref.mxfp4_mm(g[f"A_{tag}"], g[f"B_{tag}"], g[f"sA_{tag}"], g[f"sB_{tag}"])
+    assert got.shape == want.shape and np.array_equal(got, want)
