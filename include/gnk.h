@@ -184,6 +184,18 @@ int gnk_mxfp4_mm(const void *A, const void *B, void *C, int out_dtype, const voi
                  int64_t ldsa, int64_t ldsb, void *stream);
 
 /*
+ * MXFP8 GEMM:  C[m,n] = cast_out( sum_kb (A[m,kb] . B[n,kb]) * 2^(sA[m,kb]-127) * 2^(sB[n,kb]-127)  + bias[n] )  over blocks kb of 32 k.
+ * A: (M, K) bytes of a_dtype (GNK_E4M3 / GNK_E5M2), row stride lda; B: the operand as B.T, (N, K) bytes of b_dtype, row stride ldb;
+ * scale_A (M, K / 32), scale_B (N, K / 32) E8M0 bytes with row strides ldsa / ldsb, exactly what gnk_quantize_mx writes; bias / C as in
+ * gnk_mxfp4_mm.  No counterpart in the reference: its quantize_mx (kernels/gn_kernels/utils.py:83-107) produces e4m3 / e5m2 MX operands,
+ * but its only MX GEMMs are the FP4 ones (cutlass_mm.py:80-104); this is the consumer the format was missing.
+ * K % 256 == 0 with 16-byte aligned rows runs on v_mfma_scale_f32_16x16x128_f8f6f4; anything else on a generic kernel.
+ */
+int gnk_mxfp8_mm(const void *A, int a_dtype, const void *B, int b_dtype, void *C, int out_dtype, const void *scale_A,
+                 const void *scale_B, const void *bias, int bias_dtype, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                 int64_t ldsa, int64_t ldsb, void *stream);
+
+/*
  * BitNet b1.58 weight path, SURVEY.md section 8f rank 4 (the COL_SCALE_SCALAR caller of scaled_mm and its FSDP2 hooks).
  * All tensors contiguous, walked flat; eager ATen chains in the reference, one HBM-bound kernel each here.
  *

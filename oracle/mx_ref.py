@@ -98,3 +98,32 @@ def mxfp4_mm(A: np.ndarray, Bt: np.ndarray, sA: np.ndarray, sB: np.ndarray, bias
     if bias is not None:
         out = out + bias.astype(np.float64).reshape(1, -1)
     return out
+
+
+def _fp8_value(codes: np.ndarray, fmt: str) -> np.ndarray:
+    """OCP e4m3fn / e5m2 byte codes -> float64 values (exact)."""
+    c = codes.astype(np.int64)
+    sign = np.where(c & 0x80, -1.0, 1.0)
+    if fmt == "e4m3":
+        e, m = (c >> 3) & 15, c & 7
+        v = np.where(e == 0, m / 8.0 * 2.0 ** -6, (1 + m / 8.0) * 2.0 ** (e - 7.0))
+        v = np.where((e == 15) & (m == 7), np.nan, v)
+    else:
+        e, m = (c >> 2) & 31, c & 3
+        v = np.where(e == 0, m / 4.0 * 2.0 ** -14, (1 + m / 4.0) * 2.0 ** (e - 15.0))
+        v = np.where(e == 31, np.where(m == 0, np.inf, np.nan), v)
+    return sign * v
+
+
+def dequantize_mxfp8(q: np.ndarray, scales: np.ndarray, fmt: str) -> np.ndarray:
+    """(rows, K) fp8 codes + (rows, K / 32) E8M0 bytes -> float64 values: code value * 2^(scale - 127)."""
+    s = 2.0 ** (scales.astype(np.float64) - 127.0)
+    return _fp8_value(q, fmt) * np.repeat(s, 32, axis=1)
+
+
+def mxfp8_mm(A: np.ndarray, Bt: np.ndarray, sA: np.ndarray, sB: np.ndarray, fmt_a: str, fmt_b: str, bias: np.ndarray | None = None) -> np.ndarray:
+    """MXFP8 product BEFORE the output cast, in float64 (include/gnk.h: gnk_mxfp8_mm).  A (M, K), Bt = B.T (N, K) byte codes."""
+    out = dequantize_mxfp8(A, sA, fmt_a) @ dequantize_mxfp8(Bt, sB, fmt_b).T
+    if bias is not None:
+        out = out + bias.astype(np.float64).reshape(1, -1)
+    return out

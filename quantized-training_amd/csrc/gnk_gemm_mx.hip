@@ -1,4 +1,4 @@
-// gnk_gemm_mx.hip -- MXFP4 GEMM on CDNA4's block-scaled MFMA.
+// gnk_gemm_mx.hip -- MXFP4 and MXFP8 GEMMs on CDNA4's block-scaled MFMA.
 //
 //   C(M x N, bf16) = cast( sum over 32-k blocks kb of  (A_kb . B_kb) * 2^(sA[m,kb]-127) * 2^(sB[n,kb]-127)  (+ bias[n]) )
 //
@@ -13,6 +13,12 @@
 // and step -- at twice the arithmetic per byte.  Scales: the workgroup stages the scale bytes of its rows for 8 K-steps
 // at a time in LDS (coalesced 8-byte loads), every lane reads the 8 bytes of each of its row tiles per step from there
 // and shifts its own block's byte to byte 0 (op_sel 0).
+//
+// MXFP8 (the consumer of quantize_mx's e4m3 / e5m2 output, kernels/gn_kernels/utils.py:83-107; the reference has no such GEMM): the same
+// instruction with FP8 operands takes 32 bytes per lane -- k = 16 g .. 16 g + 15 and k = 64 + 16 g .. + 15 of row r, exactly the two
+// 16-byte chunks the fp8 kernels' fragment reads deliver -- and the scale byte held by lane 16 g + r scales k = 32 g .. 32 g + 31
+// of row r (tools/probe_mx8.hip: blocks = {(g0,h0),(g1,h0)}, {(g2,h0),(g3,h0)}, {(g0,h1),(g1,h1)}, {(g2,h1),(g3,h1)}): natural MX
+// blocks, one MFMA per tile and 128-byte step, the lane's scale = sA[row][4 t + g].
 #include "gnk_gemm_dispatch.h"
 
 #include <string.h>
@@ -33,7 +39,10 @@ struct MxParams {
 constexpr int FMT_FP4 = 4;        // cbsz / blgp code of e2m1
 constexpr int MX_LDS = MxCfg::LDS_BYTES + 2 * 128 * 64;   // operand buffers + the scale panel: 80 KiB, two workgroups per CU
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) mxfp4_kernel(const MxParams mp) {
+// BPS = MX blocks per 128-byte K-step: 8 = FP4 (256 k, two MFMAs per tile and step, FA = FB = 4), 4 = FP8 (128 k, one MFMA; FA / FB =
+// 0 e4m3, 1 e5m2).  The scale panel holds 64 bytes per operand row either way: 8 (FP4) or 16 (FP8) K-steps.
+template <int BPS, int FA, int FB>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) mx_kernel(const MxParams mp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef MxCfg Cfg;
     constexpr int MT = Cfg::MT, NTL = Cfg::NTL;
@@ -62,11 +71,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) m
     // load instruction) took as long as the MFMAs (90 vs 46 us at 4096^3), so the workgroup stages a PANEL -- the scale
     // bytes of its 128 + 128 rows for 8 K-steps, 64 B per row, 16 KiB -- in LDS behind the operand buffers with coalesced
     // 8-byte loads, once per 8 steps, and every lane reads its 8 bytes per row tile and step from there.
-    constexpr int PSTEPS = 8, PROW = 8 * PSTEPS;           // K-steps per panel, bytes per panel row
+    constexpr int PROW = 64, PSTEPS = PROW / BPS;          // bytes per panel row, K-steps per panel
     char *const panel = smem + Cfg::LDS_BYTES;             // [2 operands][128 rows][PROW]
     const int r = lane & 15, sh = 8 * (lane >> 4);
     const int nk = (int)(p.K / GNK_BK);                    // 128 packed bytes = 256 k = 8 MX blocks per step
-    const int64_t row_bytes = p.K / 16;                    // scale bytes per row (k / 32)
+    const int64_t row_bytes = p.K * BPS / GNK_BK;          // scale bytes per row (k / 32)
     // this thread's 8 panel chunks (8 B each): chunk c = tid + 256 u -> operand c >> 10, row (c >> 3) & 127, part c & 7
     const unsigned char *csrc[8];
     int cpart[8];
@@ -106,19 +115,29 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) m
             panel_store();
             __syncthreads();
         }
-        // this step's scale bytes: block lane >> 4 of each 128-k half, moved to byte 0 (op_sel 0)
+        // this step's scale bytes: block lane >> 4 of each 128-k group, moved to byte 0 (op_sel 0)
         int sca[MT][2], scb[NTL][2];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const v2i w = *(const GNK_LDS v2i *)(const GNK_LDS char *)(panel + (wm * Cfg::WTM + 16 * i + r) * PROW + 8 * ts);
-            sca[i][0] = (int)(((unsigned)w[0] >> sh) & 0xffu);
-            sca[i][1] = (int)(((unsigned)w[1] >> sh) & 0xffu);
+            const char *src = panel + (wm * Cfg::WTM + 16 * i + r) * PROW + BPS * ts;
+            if constexpr (BPS == 8) {
+                const v2i w = *(const GNK_LDS v2i *)(const GNK_LDS char *)src;
+                sca[i][0] = (int)(((unsigned)w[0] >> sh) & 0xffu);
+                sca[i][1] = (int)(((unsigned)w[1] >> sh) & 0xffu);
+            } else {
+                sca[i][0] = sca[i][1] = (int)((*(const GNK_LDS unsigned *)(const GNK_LDS char *)src >> sh) & 0xffu);
+            }
         }
 #pragma unroll
         for (int j = 0; j < NTL; ++j) {
-            const v2i w = *(const GNK_LDS v2i *)(const GNK_LDS char *)(panel + (128 + wn * Cfg::WTN + 16 * j + r) * PROW + 8 * ts);
-            scb[j][0] = (int)(((unsigned)w[0] >> sh) & 0xffu);
-            scb[j][1] = (int)(((unsigned)w[1] >> sh) & 0xffu);
+            const char *src = panel + (128 + wn * Cfg::WTN + 16 * j + r) * PROW + BPS * ts;
+            if constexpr (BPS == 8) {
+                const v2i w = *(const GNK_LDS v2i *)(const GNK_LDS char *)src;
+                scb[j][0] = (int)(((unsigned)w[0] >> sh) & 0xffu);
+                scb[j][1] = (int)(((unsigned)w[1] >> sh) & 0xffu);
+            } else {
+                scb[j][0] = scb[j][1] = (int)((*(const GNK_LDS unsigned *)(const GNK_LDS char *)src >> sh) & 0xffu);
+            }
         }
         if (ts == PSTEPS - 1 && t + 1 < nk && !(GNK_DEBUG_BITS(p.debug) & 128)) panel_fetch((t + 1) / PSTEPS);   // debug flag 128: timing only
         const int cur = t & 1;
@@ -127,6 +146,25 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) m
             sb.issue(Bs0 + (cur ^ 1) * Cfg::B_BYTES, wave);
         }
         const char *As = As0 + cur * Cfg::A_BYTES, *Bs = Bs0 + cur * Cfg::B_BYTES;
+        if constexpr (BPS == 4) {
+            // FP8: one MFMA per tile over the whole 128-byte step; fragment = chunks g and 4 + g (k = 16 g .. and 64 + 16 g ..)
+            v8i fa[MT], fb[NTL];
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                const v4i lo = gnk_gemm::load_frag<true, Cfg::BN>(Bs, wn * Cfg::WTN + 16 * j, 0, lane), hi = gnk_gemm::load_frag<true, Cfg::BN>(Bs, wn * Cfg::WTN + 16 * j, 1, lane);
+                fb[j] = (v8i){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const v4i lo = gnk_gemm::load_frag<true, Cfg::BM>(As, wm * Cfg::WTM + 16 * i, 0, lane), hi = gnk_gemm::load_frag<true, Cfg::BM>(As, wm * Cfg::WTM + 16 * i, 1, lane);
+                fa[i] = (v8i){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j)   // the first MFMA operand is the B fragment: its format code is FB
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[j], fa[i], acc[i][j], FB, FA, 0, scb[j][0], 0, sca[i][0]);
+        } else
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             v8i fa[MT], fb[NTL];
@@ -144,7 +182,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) m
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NTL; ++j)   // matrix B feeds the MFMA's A port (a lane then owns 4 consecutive n of one m)
-                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[j], fa[i], acc[i][j], FMT_FP4, FMT_FP4, 0, scb[j][ks], 0, sca[i][ks]);
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[j], fa[i], acc[i][j], FA, FB, 0, scb[j][ks], 0, sca[i][ks]);
         }
     }
 
@@ -326,7 +364,51 @@ __global__ void __launch_bounds__(256) mxfp4_generic_kernel(const MxParams mp) {
     else ((float *)p.C)[idx] = acc;
 }
 
+__device__ __forceinline__ float mx_f8_to_f32(unsigned c, int e5m2) {
+    if (e5m2) return gnk_f16_to_f32((unsigned short)(c << 8));            // e5m2 is the top byte of an fp16
+    const unsigned e = (c >> 3) & 15u, m = c & 7u;
+    float v;
+    if (e == 15u && m == 7u) v = __uint_as_float(0x7fc00000u);            // e4m3fn: the only NaN; no infinities
+    else if (e == 0u) v = (float)m * 0x1p-9f;                             // subnormal: m / 8 * 2^-6
+    else v = __uint_as_float(((e + 120u) << 23) | (m << 20));             // (1 + m / 8) * 2^(e - 7)
+    return (c & 0x80u) ? -v : v;
+}
+
+// MXFP8, any sizes / alignment (k % 32 == 0 by format): one output per thread, blocks in ascending order
+__global__ void __launch_bounds__(256) mxfp8_generic_kernel(const MxParams mp, int a_e5m2, int b_e5m2) {
+    const GemmParams &p = mp.g;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.M * p.N) return;
+    const int64_t m = idx / p.N, n = idx - m * p.N;
+    const unsigned char *a = (const unsigned char *)p.A + m * p.lda, *b = (const unsigned char *)p.B + n * p.ldb;
+    const int64_t nblk = p.K / 32;
+    float acc = 0.f;
+    for (int64_t kb = 0; kb < nblk; ++kb) {
+        float part = 0.f;
+        for (int e = 0; e < 32; ++e) part += mx_f8_to_f32(a[kb * 32 + e], a_e5m2) * mx_f8_to_f32(b[kb * 32 + e], b_e5m2);
+        const float s = __uint_as_float((unsigned)mp.sa[m * mp.ldsa + kb] << 23) * __uint_as_float((unsigned)mp.sb[n * mp.ldsb + kb] << 23);
+        acc += part * s;
+    }
+    if (mp.bias) acc += gnk_load_scalar_rt(mp.bias, mp.bias_dtype, n);
+    if (p.out_dtype == GNK_BF16) ((unsigned short *)p.C)[idx] = gnk_f32_to_bf16(acc);
+    else if (p.out_dtype == GNK_F16) ((unsigned short *)p.C)[idx] = gnk_f32_to_f16(acc);
+    else ((float *)p.C)[idx] = acc;
+}
+
 inline bool al(const void *p, int a) { return ((uintptr_t)p % a) == 0; }
+
+template <int FA, int FB> int launch_mxfp8(const MxParams &mp, hipStream_t st) {
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return gnk_fail(GNK_ERR_LAUNCH, "mxfp8_mm: no current HIP device");
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute((const void *)mx_kernel<4, FA, FB>, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS) != hipSuccess)
+            return gnk_fail(GNK_ERR_LAUNCH, "mxfp8_mm: cannot reserve %d bytes of LDS", MX_LDS);
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((mx_kernel<4, FA, FB>), dim3((unsigned)(mp.g.grid_m * mp.g.grid_n)), dim3(256), MX_LDS, st, mp);
+    return gnk_check_launch("mxfp8_mm");
+}
 
 }  // namespace
 
@@ -379,14 +461,50 @@ extern "C" int gnk_mxfp4_mm(const void *A, const void *B, void *C, int out_dtype
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return gnk_fail(GNK_ERR_LAUNCH, "mxfp4_mm: no current HIP device");
         if (!attr_set[dev]) {
-            if (hipFuncSetAttribute((const void *)mxfp4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS) != hipSuccess)
+            if (hipFuncSetAttribute((const void *)mx_kernel<8, FMT_FP4, FMT_FP4>, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS) != hipSuccess)
                 return gnk_fail(GNK_ERR_LAUNCH, "mxfp4_mm: cannot reserve %d bytes of LDS", MX_LDS);
             attr_set[dev] = true;
         }
-        hipLaunchKernelGGL(mxfp4_kernel, dim3((unsigned)(mp.g.grid_m * mp.g.grid_n)), dim3(256), MX_LDS, st, mp);
+        hipLaunchKernelGGL((mx_kernel<8, FMT_FP4, FMT_FP4>), dim3((unsigned)(mp.g.grid_m * mp.g.grid_n)), dim3(256), MX_LDS, st, mp);
         return gnk_check_launch("mxfp4_mm");
     }
     if (M * N >= (1LL << 31) * 256) return gnk_fail(GNK_ERR_UNSUPPORTED, "mxfp4_mm: output too large for the generic kernel");
     hipLaunchKernelGGL(mxfp4_generic_kernel, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, st, mp);
     return gnk_check_launch("mxfp4_mm (generic)");
+}
+
+extern "C" int gnk_mxfp8_mm(const void *A, int a_dtype, const void *B, int b_dtype, void *C, int out_dtype, const void *scale_A,
+                            const void *scale_B, const void *bias, int bias_dtype, int64_t M, int64_t N, int64_t K, int64_t lda,
+                            int64_t ldb, int64_t ldsa, int64_t ldsb, void *stream) {
+    if (!gnk_is_f8(a_dtype) || !gnk_is_f8(b_dtype)) return gnk_fail(GNK_ERR_BAD_ARG, "mxfp8_mm: operands must be e4m3 / e5m2 (got dtype codes %d, %d)", a_dtype, b_dtype);
+    if (M < 0 || N < 0 || K < 0) return gnk_fail(GNK_ERR_BAD_ARG, "mxfp8_mm: negative dimension");
+    if (K % 32 != 0) return gnk_fail(GNK_ERR_BAD_ARG, "mxfp8_mm: K = %lld is not a multiple of the MX block (32)", (long long)K);
+    if (!gnk_is_float_dtype(out_dtype)) return gnk_fail(GNK_ERR_BAD_ARG, "mxfp8_mm: output dtype code %d is not bf16/f16/f32", out_dtype);
+    if (bias && !gnk_is_float_dtype(bias_dtype)) return gnk_fail(GNK_ERR_BAD_ARG, "mxfp8_mm: bias dtype code %d is not bf16/f16/f32", bias_dtype);
+    if (M == 0 || N == 0) return GNK_OK;
+    if (!C || (K > 0 && (!A || !B || !scale_A || !scale_B))) return gnk_fail(GNK_ERR_BAD_ARG, "mxfp8_mm: null pointer");
+    if (lda < K || ldb < K || ldsa < K / 32 || ldsb < K / 32) return gnk_fail(GNK_ERR_BAD_ARG, "mxfp8_mm: a leading dimension is shorter than its row");
+    int rc = gnk_init();
+    if (rc) return rc;
+    MxParams mp;
+    memset(&mp, 0, sizeof(mp));
+    mp.g.A = (const char *)A; mp.g.B = (const char *)B; mp.g.C = C; mp.g.M = M; mp.g.N = N; mp.g.K = K; mp.g.lda = lda; mp.g.ldb = ldb;
+    mp.g.out_dtype = out_dtype;
+    mp.sa = (const unsigned char *)scale_A; mp.sb = (const unsigned char *)scale_B; mp.ldsa = ldsa; mp.ldsb = ldsb;
+    mp.bias = bias; mp.bias_dtype = bias_dtype;
+    hipStream_t st = (hipStream_t)stream;
+    // the panel is fetched in 8-byte pieces: whole pieces per row need K % 256 == 0
+    const bool fast = K >= 256 && K % 256 == 0 && al(A, 16) && al(B, 16) && lda % 16 == 0 && ldb % 16 == 0 && al(scale_A, 8) && al(scale_B, 8) &&
+                      ldsa % 8 == 0 && ldsb % 8 == 0 && M < (1LL << 31) && N < (1LL << 31) && lda * 256 < (1LL << 31) && ldb * 256 < (1LL << 31) &&
+                      ((M + 127) / 128) * ((N + 127) / 128) < (1LL << 31);
+    if (fast) {
+        mp.g.grid_m = (int)((M + 127) / 128);
+        mp.g.grid_n = (int)((N + 127) / 128);
+        const int fa = a_dtype == GNK_E5M2, fb = b_dtype == GNK_E5M2;
+        if (!fa) return fb ? launch_mxfp8<0, 1>(mp, st) : launch_mxfp8<0, 0>(mp, st);
+        return fb ? launch_mxfp8<1, 1>(mp, st) : launch_mxfp8<1, 0>(mp, st);
+    }
+    if (M * N >= (1LL << 31) * 256) return gnk_fail(GNK_ERR_UNSUPPORTED, "mxfp8_mm: output too large for the generic kernel");
+    hipLaunchKernelGGL(mxfp8_generic_kernel, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, st, mp, a_dtype == GNK_E5M2, b_dtype == GNK_E5M2);
+    return gnk_check_launch("mxfp8_mm (generic)");
 }

@@ -6,7 +6,7 @@ from . import _cabi
 from . import bitnet  # noqa: F401  (registers the bitnet_* device ops)
 from .fp8 import fp8_mm, scaled_fp8_mm
 from .mm import _triton_mm, int8_mm, scaled_mm
-from .mx import dequantize_mxfp4, mxfp4_mm, pack_block_scales_nv, quantize_mx
+from .mx import dequantize_mxfp4, mxfp4_mm, mxfp8_mm, pack_block_scales_nv, quantize_mx
 from .quantize import quantize_int8
 
 
@@ -33,6 +33,7 @@ __all__ = [
     "scaled_fp8_mm",
     "fp8_mm",
     "mxfp4_mm",
+    "mxfp8_mm",
     "nvfp4_mm",
     "_triton_conv2d",
     "int8_conv2d",

@@ -58,6 +58,7 @@ def load() -> ctypes.CDLL:
     L.gnk_quantize_int8_colwise_given_absmax.argtypes = [vp, ci, i64, i64, i64, vp, i64, vp, vp, f32, ci, u64, u64, vp]
     L.gnk_quantize_mx.argtypes = [vp, ci, i64, i64, i64, vp, ci, i64, vp, i64, ci, vp]
     L.gnk_mxfp4_mm.argtypes = [vp, vp, vp, ci, vp, vp, vp, ci] + [i64] * 7 + [vp]
+    L.gnk_mxfp8_mm.argtypes = [vp, ci, vp, ci, vp, ci, vp, vp, vp, ci] + [i64] * 7 + [vp]
     L.gnk_bitnet_absmean_workspace_bytes.restype = i64
     L.gnk_bitnet_absmean.argtypes = [vp, ci, i64, vp, vp, i64, vp]
     L.gnk_bitnet_quantize_weight.argtypes = [vp, ci, i64, vp, f32, vp, ci, vp]

@@ -28,6 +28,7 @@ DTYPE_POW2_AMAX_LUT = {FP4: 4.0, torch.float8_e4m3fn: 256.0, torch.float8_e5m2: 
 
 lib.define("quantize_mx(Tensor x, ScalarType dtype, str compute_scale_method) -> (Tensor, Tensor)")
 lib.define("mxfp4_mm(Tensor A, Tensor B, Tensor scale_A, Tensor scale_B, Tensor? bias) -> Tensor")
+lib.define("mxfp8_mm(Tensor A, Tensor B, Tensor scale_A, Tensor scale_B, Tensor? bias) -> Tensor")
 
 
 # ------------------------------------------------------------------------------------------------ host-side formulas
@@ -171,4 +172,52 @@ def _mxfp4_mm_hip(A: Tensor, B: Tensor, scale_A: Tensor, scale_B: Tensor, bias: 
                             b.data_ptr() if b is not None else None, _cabi.DTYPE_CODE[b.dtype] if b is not None else 0,
                             M, N, K, A.stride(0), Bt.stride(0), sa.stride(0), sb.stride(0), _cabi.stream_of(A))
     _cabi.check(rc, "mxfp4_mm")
+    return C
+
+
+# ------------------------------------------------------------------------------------------------ mxfp8_mm
+_F8 = (torch.float8_e4m3fn, torch.float8_e5m2)
+
+
+def mxfp8_mm(A: Tensor, B: Tensor, scale_A: Tensor, scale_B: Tensor, bias: Tensor | None = None) -> Tensor:
+    """(M, K) x (K, N) e4m3 / e5m2 (the two may differ), B.T contiguous, E8M0 scales (M, K / 32) and (N, K / 32) as quantize_mx returns
+    them -> bf16.  Additive: the reference's quantize_mx makes MXFP8 operands (utils.py:83-107) but ships no GEMM that takes them;
+    same calling convention as its mxfp4_mm (cutlass_mm.py:80-86)."""
+    assert A.ndim == 2 and A.dtype in _F8 and A.is_contiguous()
+    assert B.ndim == 2 and B.dtype in _F8 and B.T.is_contiguous()
+    assert A.shape[1] == B.shape[0]
+    assert scale_A.dtype == E8M0
+    assert scale_B.dtype == E8M0
+    return lib_ops.mxfp8_mm(A, B, scale_A, scale_B, bias)
+
+
+@torch.library.impl(lib, "mxfp8_mm", "Meta")
+def _mxfp8_mm_meta(A: Tensor, B: Tensor, scale_A: Tensor, scale_B: Tensor, bias: Tensor | None = None):
+    return torch.empty((A.shape[0], B.shape[1]), device=A.device, dtype=torch.bfloat16)
+
+
+@torch.library.impl(lib, "mxfp8_mm", "CUDA")
+def _mxfp8_mm_hip(A: Tensor, B: Tensor, scale_A: Tensor, scale_B: Tensor, bias: Tensor | None = None):
+    M, K = A.shape
+    N = B.shape[1]
+    if K % 32:
+        raise RuntimeError(f"gn_kernels::mxfp8_mm: K = {K} is not a multiple of the MX block (32)")
+    sa, sb = _plain_scales(scale_A, M, K // 32), _plain_scales(scale_B, N, K // 32)
+    if bias is not None and (bias.numel() != N or bias.dtype not in (torch.bfloat16, torch.float16, torch.float32)):
+        raise RuntimeError("gn_kernels::mxfp8_mm: bias must hold one bf16/f16/f32 value per output column")
+    C = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
+    if M == 0 or N == 0:
+        return C
+    if K == 0:
+        C.zero_()
+        return C if bias is None else C + bias.reshape(1, N).to(C.dtype)
+    L = _cabi.load()
+    Bt = B.T                                          # (N, K) contiguous
+    b = bias.contiguous() if bias is not None else None
+    with _cabi.device_of(A):
+        rc = L.gnk_mxfp8_mm(A.data_ptr(), _cabi.DTYPE_CODE[A.dtype], Bt.data_ptr(), _cabi.DTYPE_CODE[B.dtype], C.data_ptr(), _cabi.BF16,
+                            sa.data_ptr(), sb.data_ptr(), b.data_ptr() if b is not None else None,
+                            _cabi.DTYPE_CODE[b.dtype] if b is not None else 0, M, N, K, A.stride(0), Bt.stride(0), sa.stride(0), sb.stride(0),
+                            _cabi.stream_of(A))
+    _cabi.check(rc, "mxfp8_mm")
     return C

@@ -139,3 +139,75 @@ def test_mxfp4_mm_against_the_reference_derived_golden(tag):
         want = g[f"C_{tag}"] + (b.float().numpy().astype(np.float64)[None, :] if b is not None else 0.0)
         bound = 1.6e-2 * np.abs(want) + 2e-5 * g[f"mag_{tag}"] + 1e-5
         assert (np.abs(got - want) <= bound).all(), f"worst excess {(np.abs(got - want) - bound).max():.3e}"
+
+
+# ------------------------------------------------------------------------------------------------ MXFP8 GEMM (VERDICT r1 missing #3)
+_F8 = {"e4m3": torch.float8_e4m3fn, "e5m2": torch.float8_e5m2}
+
+
+def _check_mm8(A, Bt, sA, sB, fa, fb, bias=None):
+    """A (M, K), Bt (N, K) uint8 codes on the host; compares the HIP op with the float64 oracle under the stated fp8 tolerance."""
+    got = mx.mxfp8_mm(A.to(DEV).view(_F8[fa]), Bt.to(DEV).view(_F8[fb]).T, sA.to(DEV).view(mx.E8M0), sB.to(DEV).view(mx.E8M0),
+                      bias.to(DEV) if bias is not None else None)
+    assert got.dtype is torch.bfloat16 and got.shape == (A.shape[0], Bt.shape[0])
+    want = mx_ref.mxfp8_mm(A.numpy(), Bt.numpy(), sA.numpy(), sB.numpy(), fa, fb, bias.float().numpy() if bias is not None else None)
+    mag = np.abs(mx_ref.dequantize_mxfp8(A.numpy(), sA.numpy(), fa)) @ np.abs(mx_ref.dequantize_mxfp8(Bt.numpy(), sB.numpy(), fb)).T
+    err = np.abs(got.float().cpu().numpy().astype(np.float64) - want)
+    bound = 1.6e-2 * np.abs(want) + 5e-5 * mag + 1e-5
+    assert (err <= bound).all(), f"{int((err > bound).sum())} elements outside the tolerance; worst excess {(err - bound).max():.3e}"
+    return got
+
+
+def _mx8_case(M, N, K, seed, fa, fb):
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn(M, K, generator=g).to(_F8[fa]).view(torch.uint8)          # finite codes only
+    Bt = torch.randn(N, K, generator=g).to(_F8[fb]).view(torch.uint8)
+    sA = torch.randint(121, 133, (M, K // 32), dtype=torch.uint8, generator=g)
+    sB = torch.randint(121, 133, (N, K // 32), dtype=torch.uint8, generator=g)
+    return A, Bt, sA, sB
+
+
+@pytest.mark.parametrize("tag", ["mfma_e4m3_e4m3", "mfma_e5m2_e4m3", "mfma_e4m3_e5m2", "generic_e4m3_e4m3", "generic_e5m2_e4m3"])
+def test_mxfp8_mm_against_the_reference_derived_golden(tag):
+    """g10: operands = the reference's quantize_mx output (e4m3 / e5m2 + E8M0), expectation = their exact product.  STATED TOLERANCE as for
+    every fp8 product here: 1.6e-2 |want| + 5e-5 sum|a b| + 1e-5."""
+    g = load("g10_mxfp4_mm.npz")
+    fa, fb = tag.split("_")[1:]
+    k = f"f8_{tag}"
+    A, B = torch.from_numpy(g[f"A_{k}"]).to(DEV).view(_F8[fa]), torch.from_numpy(g[f"B_{k}"]).to(DEV).view(_F8[fb])
+    sA, sB = torch.from_numpy(g[f"sA_{k}"]).to(DEV).view(mx.E8M0), torch.from_numpy(g[f"sB_{k}"]).to(DEV).view(mx.E8M0)
+    got = mx.mxfp8_mm(A, B.T, sA, sB).float().cpu().numpy().astype(np.float64)
+    want = g[f"C_{k}"]
+    bound = 1.6e-2 * np.abs(want) + 5e-5 * g[f"mag_{k}"] + 1e-5
+    assert (np.abs(got - want) <= bound).all(), f"worst excess {(np.abs(got - want) - bound).max():.3e}"
+
+
+@pytest.mark.parametrize("fmts", [("e4m3", "e4m3"), ("e5m2", "e4m3"), ("e4m3", "e5m2"), ("e5m2", "e5m2")])
+@pytest.mark.parametrize("shape", [(128, 128, 256), (256, 384, 1024), (300, 200, 512), (1, 8, 256), (130, 70, 4352), (64, 48, 32), (33, 17, 96), (100, 52, 384)])
+def test_mxfp8_mm_vs_oracle(shape, fmts):
+    """MFMA path (K % 256 == 0; more than one 16-step scale panel at K = 4352; ragged M / N) and the generic kernel (other K)."""
+    M, N, K = shape
+    _check_mm8(*_mx8_case(M, N, K, M * 3 + N + K, *fmts), *fmts)
+
+
+def test_mxfp8_mm_scale_map_bias_and_end_to_end():
+    """One scale raised per (row, block): every MX block must be scaled by ITS byte (the lane map of tools/probe_mx8.hip), for both operands;
+    then bias, and quantize_mx -> mxfp8_mm against the fp32 product of the unquantized matrices."""
+    M, N, K = 128, 128, 512
+    A, Bt, sA, sB = _mx8_case(M, N, K, 5, "e4m3", "e4m3")
+    sA[:], sB[:] = 127, 127
+    for blk in range(K // 32):
+        sA2, sB2 = sA.clone(), sB.clone()
+        sA2[blk % M, blk] = 131
+        sB2[(3 * blk) % N, blk] = 124
+        _check_mm8(A, Bt, sA2, sB2, "e4m3", "e4m3")
+    bias = torch.randn(N).bfloat16()
+    _check_mm8(A, Bt, sA, sB, "e4m3", "e4m3", bias=bias)
+    torch.manual_seed(0)
+    X, W = torch.randn(512, 1024, device=DEV).bfloat16(), torch.randn(768, 1024, device=DEV).bfloat16()
+    xq, xs = mx.quantize_mx(X, torch.float8_e4m3fn)
+    wq, ws = mx.quantize_mx(W, torch.float8_e4m3fn)
+    out = mx.mxfp8_mm(xq, wq.T, xs, ws)
+    ref = X.float() @ W.float().T
+    rel = (out.float() - ref).norm() / ref.norm()
+    assert rel.item() < 0.05, rel.item()          # e4m3 (3 mantissa bits) on Gaussian data: ~3 % relative error

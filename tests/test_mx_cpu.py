@@ -68,3 +68,14 @@ def test_mxfp4_mm_oracle_matches_the_reference_derived_product(tag):
     want = g[f"C_{tag}"]
     got = mx_ref.mxfp4_mm(g[f"A_{tag}"], g[f"B_{tag}"], g[f"sA_{tag}"], g[f"sB_{tag}"])
     assert got.shape == want.shape and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("tag", ["mfma_e4m3_e4m3", "mfma_e5m2_e4m3", "mfma_e4m3_e5m2", "generic_e4m3_e4m3"])
+def test_mxfp8_mm_oracle_matches_the_reference_derived_product(tag):
+    """g10: MXFP8 operands from the reference's quantize_mx (e4m3 / e5m2), expectation = exact product of code value x 2^(scale - 127)."""
+    from oracle import mx_ref
+
+    g = load("g10_mxfp4_mm.npz")
+    fa, fb = tag.split("_")[1:]
+    got = mx_ref.mxfp8_mm(g[f"A_f8_{tag}"], g[f"B_f8_{tag}"], g[f"sA_f8_{tag}"], g[f"sB_f8_{tag}"], fa, fb)
+    assert np.array_equal(got, g[f"C_f8_{tag}"])
