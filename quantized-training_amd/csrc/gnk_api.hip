@@ -5,6 +5,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <atomic>
+
 // ------------------------------------------------------------------ error plumbing
 static thread_local char g_err[512] = "";
 static thread_local int g_forced_variant = -1;
@@ -47,11 +49,17 @@ extern "C" int gnk_abi_version(void) { return 1; }
 extern "C" const char *gnk_last_error(void) { return g_err; }
 
 extern "C" int gnk_init(void) {
+    // every entry point calls this: after the first call on a device it is one hipGetDevice (thread-local state) and one flag load
+    static std::atomic<bool> ready[64];
+    int dev = -1;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && ready[dev].load(std::memory_order_acquire)) return GNK_OK;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return gnk_fail(GNK_ERR_LAUNCH, "no HIP device is visible: libgnk_hip.so has no CPU path");
     gnk_num_cus();
-    return gnk_quantize_noalloc_setup();   // device address of the built-in scratch buffer, once per device
+    const int rc = gnk_quantize_noalloc_setup();   // device address of the built-in scratch buffer, once per device
+    if (rc == GNK_OK && dev >= 0 && dev < 64) ready[dev].store(true, std::memory_order_release);
+    return rc;
 }
 
 extern "C" int gnk_set_gemm_variant(int variant) {

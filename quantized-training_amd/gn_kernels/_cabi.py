@@ -26,6 +26,39 @@ DTYPE_CODE = {
 
 _lib = None
 
+# ---- C++ registration of the hot operators (csrc/torch_shim/gnk_torch_ops.cpp) ------------------------------------------------------
+# Same kernels, same C ABI; only the per-call host path changes (dispatcher -> C++ -> C ABI instead of dispatcher -> Python -> ctypes).
+# GNK_NO_TORCH_SHIM=1 keeps the Python implementations (A/B timing of the host path, and the tests' second leg).
+_SHIM_PATH = Path(__file__).resolve().parent / "libgnk_torch_ops.so"
+_SHIM_OPS = ("int8_mm", "scaled_mm", "tile_scaled_mm", "quantize_int8", "quantize_int8_rowwise_colmax", "quantize_int8_colwise_given")
+_shim_loaded = None
+
+
+def torch_shim_loaded() -> bool:
+    """Load libgnk_torch_ops.so once (it registers the device implementations of _SHIM_OPS); False when switched off or not built."""
+    global _shim_loaded
+    if _shim_loaded is None:
+        _shim_loaded = False
+        if os.environ.get("GNK_NO_TORCH_SHIM", "0") in ("", "0") and not os.environ.get("GNK_LIBRARY"):
+            if _SHIM_PATH.exists() and _LIB_PATH.exists():
+                torch.ops.load_library(str(_SHIM_PATH))
+                _shim_loaded = True
+            else:
+                import warnings
+
+                warnings.warn(f"{_SHIM_PATH.name} is not built (make -C quantized-training_amd/csrc): gn_kernels ops take the slower Python "
+                              "host path (same kernels)")
+    return _shim_loaded
+
+
+def device_impl(lib, name: str):
+    """Decorator: register fn as the device ("CUDA" key) implementation of gn_kernels::name unless the C++ shim already provides it."""
+    def deco(fn):
+        if name in _SHIM_OPS and torch_shim_loaded():
+            return fn
+        return torch.library.impl(lib, name, "CUDA")(fn)
+    return deco
+
 
 def library_path() -> Path:
     return _LIB_PATH

@@ -36,7 +36,7 @@ def _int8_mm_meta(A: Tensor, B: Tensor):
     return torch.empty((A.shape[0], B.shape[1]), device=A.device, dtype=torch.int32)
 
 
-@torch.library.impl(lib, "int8_mm", "CUDA")
+@_cabi.device_impl(lib, "int8_mm")
 def _int8_mm_hip(A: Tensor, B: Tensor):
     M, K = A.shape
     N = B.shape[1]
@@ -123,13 +123,13 @@ def _scaled_mm_launch(A: Tensor, B: Tensor, row_scale: Tensor, col_scale: Tensor
     return C
 
 
-@torch.library.impl(lib, "scaled_mm", "CUDA")
+@_cabi.device_impl(lib, "scaled_mm")
 def _scaled_mm_hip(A: Tensor, B: Tensor, row_scale: Tensor, col_scale: Tensor):
     # (f32(acc) * row) * col, output dtype = scale dtype (reference triton_mm.py:382-407)
     return _scaled_mm_launch(A, B, row_scale, col_scale, row_scale.dtype, 0, "scaled_mm")
 
 
-@torch.library.impl(lib, "tile_scaled_mm", "CUDA")
+@_cabi.device_impl(lib, "tile_scaled_mm")
 def _tile_scaled_mm_hip(A: Tensor, B: Tensor, scale_A: Tensor, scale_B: Tensor):
     # block sizes from integer shape ratios (reference triton_mm.py:419,434-436)
     M, K = A.shape

@@ -64,7 +64,7 @@ def _quantize_int8_meta(x: Tensor, dim: int, stochastic_rounding: bool, eps: flo
     return q, x.new_empty(_scale_shape(x, dim))
 
 
-@torch.library.impl(lib, "quantize_int8", "CUDA")
+@_cabi.device_impl(lib, "quantize_int8")
 def _quantize_int8_hip(x: Tensor, dim: int, stochastic_rounding: bool, eps: float, rng: Tensor | None = None):
     if not supports(x, dim):
         raise RuntimeError(f"gn_kernels::quantize_int8: unsupported input (shape {tuple(x.shape)}, strides {x.stride()}, "
@@ -162,7 +162,7 @@ def _colwise_given_meta(x: Tensor, absmax: Tensor, stochastic_rounding: bool, ep
     return torch.empty_like(x, dtype=torch.int8), x.new_empty((1, x.shape[1]))
 
 
-@torch.library.impl(lib, "quantize_int8_rowwise_colmax", "CUDA")
+@_cabi.device_impl(lib, "quantize_int8_rowwise_colmax")
 def _rowwise_colmax_hip(x: Tensor, stochastic_rounding: bool, eps: float, rng: Tensor | None = None):
     if not supports_rowwise_colmax(x):
         raise RuntimeError(f"gn_kernels::quantize_int8_rowwise_colmax: unsupported input (shape {tuple(x.shape)}, strides {x.stride()}, dtype {x.dtype})")
@@ -186,7 +186,7 @@ def _rowwise_colmax_hip(x: Tensor, stochastic_rounding: bool, eps: float, rng: T
     return q, scale, colmax
 
 
-@torch.library.impl(lib, "quantize_int8_colwise_given", "CUDA")
+@_cabi.device_impl(lib, "quantize_int8_colwise_given")
 def _colwise_given_hip(x: Tensor, absmax: Tensor, stochastic_rounding: bool, eps: float, rng: Tensor | None = None):
     if not supports_colwise_given(x):
         raise RuntimeError(f"gn_kernels::quantize_int8_colwise_given: unsupported input (shape {tuple(x.shape)}, strides {x.stride()}, dtype {x.dtype})")
