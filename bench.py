@@ -228,6 +228,20 @@ def train_detail(world, rank, quick=False):
     return res
 
 
+def bare_mfma_rate():
+    """tools/probe_mfma_rate (built by __graft_entry__.build()): what a register-resident MFMA loop sustains on this chip right now."""
+    import subprocess
+
+    exe = ROOT / "tools" / "probe_mfma_rate"
+    if not exe.exists():
+        return None
+    try:
+        r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    except Exception as exc:
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -311,6 +325,15 @@ def main():
                                            "the reads beyond 33.5 MB are per-XCD re-reads served by the Infinity Cache",
                            "avg_launch_us": round(avg_ms * 1e3, 2), "median_launch_us": round(med_ms * 1e3, 2),
                            "algorithmic_ops_per_launch": 2 * S ** 3}
+        bare = bare_mfma_rate()
+        if bare and "i8_16x16x64_tops" in bare:
+            out["roofline"]["bare_mfma_loop_tops"] = bare["i8_16x16x64_tops"]
+            out["roofline"]["frac_of_bare_mfma_loop"] = round(achieved / bare["i8_16x16x64_tops"], 4)
+            out["roofline"]["bare_mfma_note"] = ("tools/probe_mfma_rate run on this GPU beside the bench: v_mfma_i32_16x16x64_i8 back to back from registers, 8 waves on "
+                                                 "every CU, random operands -- the rate the matrix pipe sustains at the clock the chip holds under this load "
+                                                 f"(fp8 16x16x128: {bare.get('f8_16x16x128_tflops')} TFLOP/s)")
+        elif bare:
+            out["roofline"]["bare_mfma_loop_tops"] = bare
         if not args.no_detail:
             detail = {}
             for (d, l), a in cases.items():
@@ -374,6 +397,14 @@ def main():
                 nxt[f"mxfp4_mm {S}^3"] = {"us": round(t_mm * 1e3, 1), "TFLOP/s": round(2 * S ** 3 / (t_mm * 1e-3) * 1e-12, 1),
                                           "frac_of_fp4_dense_peak_10066": round(2 * S ** 3 / (t_mm * 1e-3) * 1e-12 / 10066.0, 4)}
                 del A4, B4, s4a, s4b
+                A8 = torch.randn(S, S, device=dev).to(torch.float8_e4m3fn)
+                B8 = torch.randn(S, S, device=dev).to(torch.float8_e4m3fn).T
+                s8a = torch.randint(120, 134, (S, S // 32), dtype=torch.uint8, device=dev).view(mx.E8M0)
+                s8b = torch.randint(120, 134, (S, S // 32), dtype=torch.uint8, device=dev).view(mx.E8M0)
+                t_mm8 = time_kernel_graph(lambda: mx.mxfp8_mm(A8, B8, s8a, s8b), per_graph=10)
+                nxt[f"mxfp8_mm {S}^3"] = {"us": round(t_mm8 * 1e3, 1), "TFLOP/s": round(2 * S ** 3 / (t_mm8 * 1e-3) * 1e-12, 1),
+                                          "frac_of_fp8_dense_peak_5033": round(2 * S ** 3 / (t_mm8 * 1e-3) * 1e-12 / PEAK_DENSE_8BIT_TOPS, 4)}
+                del A8, B8, s8a, s8b
                 from gn_kernels import bitnet as bop
 
                 w = (torch.randn(2 * S, 2 * S, device=dev) * 0.02).bfloat16()      # BitNet weight path, 8192^2 bf16
