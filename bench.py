@@ -201,14 +201,18 @@ def train_detail(world, rank, quick=False):
 
     import train_bench
 
-    runs = [("llama-1b", ["--model", "1b", "--batch_size", "16"], 6, 2)]
+    runs = [("llama-1b", ["--model", "1b", "--batch_size", "16"], 6, 2, ("mixed_precision", "none"))]
     if world == 1:
-        runs.insert(0, ("llama-2-470m", ["--model", "470m", "--batch_size", "4"], 10, 3))
+        runs.insert(0, ("llama-2-470m", ["--model", "470m", "--batch_size", "4"], 10, 3, ("mixed_precision", "none")))
+    else:
+        # beside the reference's fixed global batch (2 sequences per GPU at N = 8: the per-GPU GEMMs shrink with N), the weak-scaling
+        # form: 16 sequences PER GPU, the per-GPU step of the N = 1 run plus the gradient all-reduce
+        runs.append((f"llama-1b weak (global batch {16 * world})", ["--model", "1b", "--batch_size", str(16 * world)], 6, 2, ("mixed_precision",)))
     res = {}
-    for name, margs, steps, warm in runs:
+    for name, margs, steps, warm, quants in runs:
         if quick:
             steps, warm = 2, 1
-        for q in ("mixed_precision", "none"):
+        for q in quants:
             key = f"{name} {'int8_mp' if q == 'mixed_precision' else 'bf16'} compiled"
             try:
                 torch._dynamo.reset()

@@ -61,8 +61,10 @@ int gnk_init(void);
  * q has strides (sqr, sqc).  sr != 0 replaces the rounding by floor(v + u), u ~ U[0,1): 24 bits of word (e & 3) of the
  * Philox4x32-10 block with key `seed` and counter e >> 2, e = r*C + c + offset (the logical element number; four
  * elements share a block).  The reference draws torch.rand_like (int8.py:21): parity under SR is statistical.
- * workspace: device buffer of >= R floats, needed only when the reduction runs along the strided
- * dimension (sxc != 1); may be NULL otherwise.  gnk_quantize_int8_workspace_bytes() tells.
+ * workspace: needed only when the reduction runs along the strided dimension (sxc != 1); may be NULL otherwise.
+ * gnk_quantize_int8_workspace_bytes() returns the size the library asks for: up to 32 rows of R fp32 words, the per-block
+ * partial maxima of pass 1 -- no need to clear it, nothing is read that the call did not write.  The minimum accepted is
+ * R * 4 bytes (one word per logical row); pass 1 then clears those words on `stream` and uses atomicMax.  Same bits either way.
  */
 int gnk_quantize_int8(const void *x, int x_dtype, int64_t R, int64_t C, int64_t sxr, int64_t sxc,
                       int8_t *q, int64_t sqr, int64_t sqc, void *scale, float eps,
@@ -232,8 +234,8 @@ int gnk_set_gemm_variant(int variant);
  * hipFree and calls no allocating routine.  Limits: a strided reduction (sxc != 1) over more than
  * gnk_quantize_int8_noalloc_max_rows() = GNK_NOALLOC_SCRATCH_BYTES / 4 logical rows is rejected with
  * GNK_ERR_UNSUPPORTED; calls that overlap on one GPU (different streams or threads) share the buffer and RACE --
- * serialise them, or use gnk_quantize_int8 with one workspace per stream.  The words used are cleared on `stream` at
- * the start of each call.
+ * serialise them, or use gnk_quantize_int8 with one workspace per stream.  Every word a call reads it has written
+ * (partial maxima) or cleared on `stream` (reductions too large for the buffer to hold partial rows) first.
  */
 #define GNK_NOALLOC_SCRATCH_BYTES (256 * 1024)
 int64_t gnk_quantize_int8_noalloc_max_rows(void);

@@ -382,21 +382,108 @@ col_absmax_kernel(const char *__restrict__ x, unsigned *__restrict__ amax_ws, in
     }
 }
 
-template <int DT, bool SR, int COL_PB, bool NT>
+// Pass 1 without atomics and without a cleared workspace (round 2; the hipMemsetAsync in front of every strided reduction was
+// ~480 fill launches per Llama-470m step): block (bx, by) owns CL column-lanes x `rpb` rows and writes ONE row of partial maxima,
+// partial[by][col]; pass 2 reduces the <= GNK_COL_PARTS partial rows of its columns itself.
+// Two geometries: CL = 32 (512-byte row segments, 8 row-lanes, 16 loads of 16 B in flight per thread -- col_absmax_kernel's) when that
+// fills the chip, CL = 8 (one 128-byte segment per row, 32 row-lanes, 8 loads in flight) for narrow matrices.
+constexpr int GNK_COL_PARTS = 32;
+template <int DT, int CL>
+__global__ void __launch_bounds__(256)
+col_absmax_partial_kernel(const char *__restrict__ x, unsigned *__restrict__ partial, int64_t P, int64_t Q, int64_t ld_bytes, int64_t rpb) {
+    constexpr int VEC = ElemTraits<DT>::VEC, RL = 256 / CL, U = CL == 32 ? 16 : 8;
+    __shared__ unsigned red[RL][CL * VEC + 1];            // fp32 bit patterns of |x| maxima (integer order: NaN > Inf > finite, GnkAbsMax)
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+    const int64_t col0 = ((int64_t)blockIdx.x * CL + cl) * VEC;
+    const int64_t row0 = (int64_t)blockIdx.y * rpb;
+    const int64_t rend = row0 + rpb < P ? row0 + rpb : P;
+    unsigned mw[4] = {0u, 0u, 0u, 0u};                     // per input dword: 2 packed 16-bit patterns, or 1 fp32 pattern
+    if (col0 < Q) {
+        const char *src = x + col0 * (16 / VEC);
+        for (int64_t r = row0 + rl; r < rend; r += RL * U) {
+            v4i raw[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t row = r + RL * u;
+                raw[u] = (v4i){0, 0, 0, 0};
+                if (row < rend) raw[u] = *(const v4i *)(src + row * ld_bytes);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (DT == GNK_F32) { const unsigned a = (unsigned)raw[u][j] & 0x7fffffffu; mw[j] = a > mw[j] ? a : mw[j]; }
+                    else mw[j] = gnk_pk_max_u16(mw[j], (unsigned)raw[u][j] & 0x7fff7fffu);
+                }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if constexpr (DT == GNK_F32) red[rl][cl * VEC + j] = mw[j];
+        else if constexpr (DT == GNK_BF16) { red[rl][cl * VEC + 2 * j] = (mw[j] & 0xffffu) << 16; red[rl][cl * VEC + 2 * j + 1] = mw[j] & 0xffff0000u; }
+        else {
+            red[rl][cl * VEC + 2 * j] = __float_as_uint(gnk_f16_to_f32((unsigned short)(mw[j] & 0xffffu)));
+            red[rl][cl * VEC + 2 * j + 1] = __float_as_uint(gnk_f16_to_f32((unsigned short)(mw[j] >> 16)));
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < CL * VEC; c += 256) {
+        unsigned v = red[0][c];
+#pragma unroll
+        for (int i = 1; i < RL; ++i) v = red[i][c] > v ? red[i][c] : v;
+        const int64_t col = (int64_t)blockIdx.x * CL * VEC + c;
+        if (col < Q) partial[(int64_t)blockIdx.y * Q + col] = v;
+    }
+}
+
+// Rows per pass-1 block and the number of partial rows (<= GNK_COL_PARTS) of a reduction over P memory rows, per geometry:
+// wide (CL = 32): whole 128-row slabs; narrow (CL = 8): a power of two >= 32.
+inline void col_partial_plan(int64_t P, bool wide, int64_t &rpb, int64_t &nparts) {
+    if (wide) {
+        const int64_t nslabs = (P + 127) / 128;
+        rpb = 128 * ((nslabs + GNK_COL_PARTS - 1) / GNK_COL_PARTS);
+    } else {
+        rpb = 32;
+        while ((P + rpb - 1) / rpb > GNK_COL_PARTS) rpb *= 2;
+    }
+    nparts = (P + rpb - 1) / rpb;
+}
+
+// PARTS: amax_ws holds `nparts` partial rows [nparts][Q] (col_absmax_partial_kernel) instead of one reduced row.
+template <int DT, bool SR, int COL_PB, bool NT, bool PARTS = false>
 __global__ void __launch_bounds__(256)
 col_quant_kernel(const char *__restrict__ x, int8_t *__restrict__ q, void *__restrict__ scale,
                  const unsigned *__restrict__ amax_ws, int64_t P, int64_t Q, int64_t ld_bytes,
-                 int64_t ldq, float eps, unsigned long long seed, unsigned long long offset) {
+                 int64_t ldq, float eps, unsigned long long seed, unsigned long long offset, int nparts) {
     constexpr int VEC = ElemTraits<DT>::VEC;
     const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int64_t col0 = ((int64_t)blockIdx.x * 32 + cl) * VEC;
     const int64_t row0 = (int64_t)blockIdx.y * COL_PB;
+    __shared__ unsigned cm[PARTS ? 32 * VEC : 1];
+    if constexpr (PARTS) {
+        // the block's 32 * VEC columns, one per thread; the partial rows are L2 hits shared by every block of this column strip
+        for (int c = threadIdx.x; c < 32 * VEC; c += 256) {
+            const int64_t col = (int64_t)blockIdx.x * 32 * VEC + c;
+            unsigned v = 0u;
+            if (col < Q) {
+                for (int g0 = 0; g0 < nparts; g0 += 8) {
+                    unsigned w[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) w[u] = g0 + u < nparts ? amax_ws[(int64_t)(g0 + u) * Q + col] : 0u;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v = w[u] > v ? w[u] : v;
+                }
+            }
+            cm[c] = v;
+        }
+        __syncthreads();
+    }
     if (col0 >= Q) return;
     GnkDivisor dv[VEC];
     bool fast = true;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-        const float s = __uint_as_float(amax_ws[col0 + j]) / 127.0f;
+        const float s = __uint_as_float(PARTS ? cm[cl * VEC + j] : amax_ws[col0 + j]) / 127.0f;
         dv[j].set(gnk_clamp_min_nan(s, eps));
         fast = fast && dv[j].ok();
         if (blockIdx.y == 0 && rl == 0) gnk_store_scalar_rt(scale, DT, col0 + j, s);
@@ -531,22 +618,39 @@ int launch_rowwise(const void *x, int8_t *q, void *scale, int64_t R, int64_t C, 
 
 template <int DT, bool SR>
 int launch_colwise(const void *x, int8_t *q, void *scale, int64_t P, int64_t Q, int64_t ld, int64_t ldq, float eps,
-                   uint64_t seed, uint64_t offset, unsigned *ws, hipStream_t st) {
+                   uint64_t seed, uint64_t offset, unsigned *ws, int64_t ws_bytes, hipStream_t st) {
     constexpr int VEC = ElemTraits<DT>::VEC;
     const int64_t ld_bytes = ld * (16 / VEC);
-    if (hipMemsetAsync(ws, 0, (size_t)Q * 4, st) != hipSuccess) return gnk_fail(GNK_ERR_LAUNCH, "quantize_int8: memset of workspace failed");
     const int64_t gx = (Q + 32 * VEC - 1) / (32 * VEC);
     const dim3 block(256);
     const bool nt = !(gnk_debug_flags_get() & 16);
-    if (gx * ((P + 127) / 128) * 2 >= (int64_t)gnk_num_cus()) {   // measured: 128-row slabs win down to 1 block per CU (4096^2, 8192 x 1024)
-        const dim3 grid((unsigned)gx, (unsigned)((P + 127) / 128));
+    const bool big = gx * ((P + 127) / 128) * 2 >= (int64_t)gnk_num_cus();   // measured: 128-row slabs win down to 1 block per CU (4096^2, 8192 x 1024)
+    const dim3 grid((unsigned)gx, (unsigned)(big ? (P + 127) / 128 : (P + 31) / 32));
+    int64_t rpb, nparts;
+    col_partial_plan(P, true, rpb, nparts);
+    // col_absmax_kernel's geometry from one block per two CUs up (tools/colwise_ab.py: 1024 x 4096 11.3 vs 14.2 us, 5632 x 2048 14.0 vs 18.1 us;
+    // 8192 x 1024, the other 128-block case, 14.1 vs 13.7 us)
+    const bool wide = gx * nparts * 2 >= (int64_t)gnk_num_cus();
+    if (!wide) col_partial_plan(P, false, rpb, nparts);
+    if (ws_bytes >= nparts * Q * 4) {
+        // partial maxima: nothing to clear, no atomics (the workspace gnk_quantize_int8_workspace_bytes asks for)
+        if (wide) hipLaunchKernelGGL((col_absmax_partial_kernel<DT, 32>), dim3((unsigned)gx, (unsigned)nparts), block, 0, st, (const char *)x, ws, P, Q, ld_bytes, rpb);
+        else hipLaunchKernelGGL((col_absmax_partial_kernel<DT, 8>), dim3((unsigned)((Q + 8 * VEC - 1) / (8 * VEC)), (unsigned)nparts), block, 0, st, (const char *)x, ws, P, Q, ld_bytes, rpb);
+        if (!big) hipLaunchKernelGGL((col_quant_kernel<DT, SR, 32, false, true>), grid, block, 0, st, (const char *)x, q, scale, ws, P, Q, ld_bytes, ldq, eps, seed, offset, (int)nparts);
+        else if (nt) hipLaunchKernelGGL((col_quant_kernel<DT, SR, 128, true, true>), grid, block, 0, st, (const char *)x, q, scale, ws, P, Q, ld_bytes, ldq, eps, seed, offset, (int)nparts);
+        else hipLaunchKernelGGL((col_quant_kernel<DT, SR, 128, false, true>), grid, block, 0, st, (const char *)x, q, scale, ws, P, Q, ld_bytes, ldq, eps, seed, offset, (int)nparts);
+        return gnk_check_launch("quantize_int8 colwise");
+    }
+    // a workspace of one word per logical row (the minimum; gnk_quantize_int8_noalloc beyond what its scratch holds as partial rows):
+    // atomicMax into words cleared on the stream first
+    if (hipMemsetAsync(ws, 0, (size_t)Q * 4, st) != hipSuccess) return gnk_fail(GNK_ERR_LAUNCH, "quantize_int8: memset of workspace failed");
+    if (big) {
         hipLaunchKernelGGL((col_absmax_kernel<DT, 128>), grid, block, 0, st, (const char *)x, ws, P, Q, ld_bytes);
-        if (nt) hipLaunchKernelGGL((col_quant_kernel<DT, SR, 128, true>), grid, block, 0, st, (const char *)x, q, scale, ws, P, Q, ld_bytes, ldq, eps, seed, offset);
-        else hipLaunchKernelGGL((col_quant_kernel<DT, SR, 128, false>), grid, block, 0, st, (const char *)x, q, scale, ws, P, Q, ld_bytes, ldq, eps, seed, offset);
+        if (nt) hipLaunchKernelGGL((col_quant_kernel<DT, SR, 128, true>), grid, block, 0, st, (const char *)x, q, scale, ws, P, Q, ld_bytes, ldq, eps, seed, offset, 0);
+        else hipLaunchKernelGGL((col_quant_kernel<DT, SR, 128, false>), grid, block, 0, st, (const char *)x, q, scale, ws, P, Q, ld_bytes, ldq, eps, seed, offset, 0);
     } else {
-        const dim3 grid((unsigned)gx, (unsigned)((P + 31) / 32));
         hipLaunchKernelGGL((col_absmax_kernel<DT, 32>), grid, block, 0, st, (const char *)x, ws, P, Q, ld_bytes);
-        hipLaunchKernelGGL((col_quant_kernel<DT, SR, 32, false>), grid, block, 0, st, (const char *)x, q, scale, ws, P, Q, ld_bytes, ldq, eps, seed, offset);
+        hipLaunchKernelGGL((col_quant_kernel<DT, SR, 32, false>), grid, block, 0, st, (const char *)x, q, scale, ws, P, Q, ld_bytes, ldq, eps, seed, offset, 0);
     }
     return gnk_check_launch("quantize_int8 colwise");
 }
@@ -588,10 +692,10 @@ int launch_colwise_given(const void *x, int8_t *q, void *scale, int64_t P, int64
     const dim3 block(256);
     if (gx * ((P + 127) / 128) * 2 >= (int64_t)gnk_num_cus()) {
         const dim3 grid((unsigned)gx, (unsigned)((P + 127) / 128));
-        hipLaunchKernelGGL((col_quant_kernel<DT, SR, 128, true>), grid, block, 0, st, (const char *)x, q, scale, amax, P, Q, ld_bytes, ldq, eps, seed, offset);
+        hipLaunchKernelGGL((col_quant_kernel<DT, SR, 128, true>), grid, block, 0, st, (const char *)x, q, scale, amax, P, Q, ld_bytes, ldq, eps, seed, offset, 0);
     } else {
         const dim3 grid((unsigned)gx, (unsigned)((P + 31) / 32));
-        hipLaunchKernelGGL((col_quant_kernel<DT, SR, 32, false>), grid, block, 0, st, (const char *)x, q, scale, amax, P, Q, ld_bytes, ldq, eps, seed, offset);
+        hipLaunchKernelGGL((col_quant_kernel<DT, SR, 32, false>), grid, block, 0, st, (const char *)x, q, scale, amax, P, Q, ld_bytes, ldq, eps, seed, offset, 0);
     }
     return gnk_check_launch("quantize_int8 colwise (given absmax)");
 }
@@ -600,10 +704,14 @@ inline bool aligned(const void *p, int a) { return ((uintptr_t)p % a) == 0; }
 
 }  // namespace
 
+// Strided reduction: the workspace asked for holds the partial maxima of pass 1 (<= GNK_COL_PARTS rows of R words: nothing to clear);
+// gnk_quantize_int8 also accepts the minimum of R * 4 bytes and then clears + atomicMax-es one word per logical row.
 extern "C" int64_t gnk_quantize_int8_workspace_bytes(int64_t R, int64_t C, int64_t sxr, int64_t sxc) {
-    (void)C;
-    if (sxc == 1 || R <= 0) return 0;
-    return sxr == 1 ? R * 4 : 0;
+    if (sxc == 1 || R <= 0 || sxr != 1) return 0;
+    int64_t rpb, na, nb;                                  // enough for either pass-1 geometry (the choice depends on the dtype too)
+    col_partial_plan(C > 0 ? C : 1, true, rpb, na);
+    col_partial_plan(C > 0 ? C : 1, false, rpb, nb);
+    return (na > nb ? na : nb) * R * 4;
 }
 
 extern "C" int gnk_quantize_int8(const void *x, int x_dtype, int64_t R, int64_t C, int64_t sxr, int64_t sxc,
@@ -638,7 +746,7 @@ extern "C" int gnk_quantize_int8(const void *x, int x_dtype, int64_t R, int64_t 
         if (!workspace || workspace_bytes < R * 4)
             return gnk_fail(GNK_ERR_WORKSPACE, "quantize_int8: strided reduction needs a workspace of %lld bytes", (long long)(R * 4));
         GNK_DISPATCH(launch_colwise, x, q, scale, /*P=*/C, /*Q=*/R, /*ld=*/sxc, /*ldq=*/sqc, eps, seed, offset,
-                     (unsigned *)workspace, st);
+                     (unsigned *)workspace, workspace_bytes, st);
     }
 #undef GNK_DISPATCH
     // anything else (C == 0 included: scale = 0, nothing to write)
@@ -682,7 +790,7 @@ extern "C" int64_t gnk_quantize_int8_noalloc_max_rows(void) { return GNK_NOALLOC
 extern "C" int gnk_quantize_int8_noalloc(const void *x, int x_dtype, int64_t R, int64_t C, int64_t sxr, int64_t sxc,
                                          int8_t *q, int64_t sqr, int64_t sqc, void *scale, float eps, int sr, uint64_t seed,
                                          uint64_t offset, void *stream) {
-    const int64_t need = gnk_quantize_int8_workspace_bytes(R, C, sxr, sxc);
+    const int64_t need = (sxc == 1 || R <= 0 || sxr != 1) ? 0 : R * 4;   // the minimum gnk_quantize_int8 accepts (one word per logical row)
     if (need > (int64_t)GNK_NOALLOC_SCRATCH_BYTES)
         return gnk_fail(GNK_ERR_UNSUPPORTED, "quantize_int8_noalloc: a strided reduction over %lld logical rows needs %lld bytes of scratch, "
                         "the built-in buffer holds %lld (at most %lld rows): use gnk_quantize_int8 with a caller workspace",
@@ -693,7 +801,8 @@ extern "C" int gnk_quantize_int8_noalloc(const void *x, int x_dtype, int64_t R, 
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !g_scratch_ptr[dev])
         return gnk_fail(GNK_ERR_LAUNCH, "quantize_int8_noalloc: no scratch address for the current device");
     void *ptr = g_scratch_ptr[dev];   // the DEVICE address; never the array's name
-    // launch_colwise clears the words it uses (hipMemsetAsync on `stream`) before pass 1, so the previous call's maxima do not leak
+    // launch_colwise either writes every partial word it later reads (small reductions) or clears the words it uses (hipMemsetAsync on
+    // `stream`) before pass 1, so the previous call's maxima do not leak
     return gnk_quantize_int8(x, x_dtype, R, C, sxr, sxc, q, sqr, sqc, scale, eps, sr, seed, offset, ptr, GNK_NOALLOC_SCRATCH_BYTES, stream);
 }
 

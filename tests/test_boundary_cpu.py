@@ -44,7 +44,8 @@ def test_cabi_rejects_bad_arguments_without_touching_a_gpu():
     rc = L.gnk_int8_mm(None, None, None, -1, 4, 4, 4, 1, 4, 1, None)
     assert rc == -1
     assert L.gnk_int8_mm(None, None, None, 0, 4, 4, 4, 1, 4, 1, None) == 0      # empty problem: nothing to do
-    assert L.gnk_quantize_int8_workspace_bytes(128, 64, 1, 128) == 512            # strided reduction: R floats
+    assert L.gnk_quantize_int8_workspace_bytes(128, 64, 1, 128) == 2 * 512        # strided reduction over 64 rows: 2 partial rows of R floats
+    assert L.gnk_quantize_int8_workspace_bytes(128, 8192, 1, 128) == 32 * 512     # never more than 32 partial rows
     assert L.gnk_quantize_int8_workspace_bytes(128, 64, 64, 1) == 0
 
 

@@ -260,3 +260,37 @@ def test_nonfinite_inputs_surface_like_the_reference(name):
     xl = x.repeat(1, 33)
     ql, sl = quantize_int8(xl, dim=1)
     check(ql[:, :512], sl, 1)
+
+
+@pytest.mark.parametrize("shape", [(5, 64), (130, 256), (1000, 1024), (2049, 512), (8192, 1024), (4100, 72)])
+@pytest.mark.parametrize("name", ["bf16", "f16", "f32"])
+def test_strided_reduction_both_workspace_forms_vs_oracle(shape, name):
+    """gnk_quantize_int8 along the strided dim runs pass 1 either as per-block partial maxima (the workspace its _workspace_bytes asks
+    for: nothing to clear, no atomics) or, given only the minimum of one word per logical row, as atomicMax into cleared words.  Both
+    through the C ABI, both bit-equal to the oracle; the partial form on a workspace full of garbage."""
+    from gn_kernels import _cabi
+
+    L = _cabi.load()
+    dt = FLOAT_DTYPES[name]
+    torch.manual_seed(shape[0] * 7 + shape[1])
+    x_cpu = (torch.randn(shape) * torch.rand(1, shape[1]) * 8).to(dt)
+    x_cpu[:, 3] = 0
+    x_cpu[shape[0] - 1, 7] = 300.0                              # a column whose maximum sits in the last (ragged) row block
+    qo, so = oracle.quantize_int8(x_cpu, dim=0)
+    x = x_cpu.to(DEV)
+    P, Q = shape                                                # logical rows = the Q columns, reduced over P
+    full = L.gnk_quantize_int8_workspace_bytes(Q, P, 1, x.stride(0))
+    assert full >= Q * 4 and full % (Q * 4) == 0 and full // (Q * 4) <= 32
+    for nbytes in (full, Q * 4):
+        ws = torch.full((full,), 0xFF, dtype=torch.uint8, device=DEV)        # garbage (NaN patterns): a form that trusts it would fail
+        q = torch.empty_like(x, dtype=torch.int8)
+        s = torch.empty(Q, dtype=dt, device=DEV)
+        rc = L.gnk_quantize_int8(x.data_ptr(), _cabi.DTYPE_CODE[dt], Q, P, 1, x.stride(0), q.data_ptr(), 1, q.stride(0), s.data_ptr(), 1e-12,
+                                 0, 0, 0, ws.data_ptr(), nbytes, _cabi.stream_of(x))
+        assert rc == 0, L.gnk_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(q.cpu(), qo), f"int8 mismatch with a {nbytes}-byte workspace"
+        assert bits_equal(s.view(1, -1), so)
+    rc = L.gnk_quantize_int8(x.data_ptr(), _cabi.DTYPE_CODE[dt], Q, P, 1, x.stride(0), q.data_ptr(), 1, q.stride(0), s.data_ptr(), 1e-12,
+                             0, 0, 0, ws.data_ptr(), Q * 4 - 1, _cabi.stream_of(x))
+    assert rc != 0 and b"workspace" in L.gnk_last_error()
