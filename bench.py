@@ -69,7 +69,7 @@ def make_inputs(S, dev):
     return cases
 
 
-PMC_TRAFFIC_BYTES = (2 * 49_298 + 32_768) * 1024   # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; see roofline.traffic_note
+PMC_TRAFFIC_BYTES = (2 * 49_296 + 32_768) * 1024   # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; see roofline.traffic_note
 
 
 def time_kernel(fn, iters=30, warm=5):
@@ -324,7 +324,7 @@ def main():
         out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_DENSE_8BIT_TOPS, "unit": "TFLOP/s",
                            "frac": round(achieved / PEAK_DENSE_8BIT_TOPS, 4), "traffic": PMC_TRAFFIC_BYTES,
                            "kernel": "gemm_pp_kernel<256x256 tile, 8 waves, 8-phase ping-pong, int8 v_mfma_i32_16x16x64_i8, A K-major, B K-major, row/col epilogue>",
-                           "traffic_note": "memory-side bytes per launch measured in separate rocprofv3 --pmc passes over this kernel (profiles/r01e_pmc_int8_nt_4096.txt): "
+                           "traffic_note": "memory-side bytes per launch measured in separate rocprofv3 --pmc passes over this kernel (profiles/r02d_pmc_int8_nt_4096.txt; round 1: r01e_pmc_int8_nt_4096.txt, same values): "
                                            "FETCH_SIZE 50.5 MB x 2 (gfx950 correction) + WRITE_SIZE 33.6 MB (= the algorithmic 32 MiB of C); algorithmic bytes 67.1 MB -- "
                                            "the reads beyond 33.5 MB are per-XCD re-reads served by the Infinity Cache",
                            "avg_launch_us": round(avg_ms * 1e3, 2), "median_launch_us": round(med_ms * 1e3, 2),
