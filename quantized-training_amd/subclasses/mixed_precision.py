@@ -80,6 +80,24 @@ class MixedPrecisionLinearWeight(Tensor):
     def __repr__(self):
         return f"{type(self).__name__}(data={self._data}, config={self.config})"
 
+    # FSDP2 (llm_pretrain.py:134-139 `fully_shard(layer)`).  The reference defines no all-gather hooks for this class; FSDP2's default path
+    # then rebuilds the unsharded parameter as a PLAIN tensor from its all-gather buffer (torch's _fsdp_param.py:init_unsharded_param), and
+    # every F.linear silently runs in bf16.  With the two hooks the all-gathered bf16 weight comes back wrapped, so the sharded model runs
+    # the same INT8 matmuls as the unsharded one (tests/test_subclasses_cpu.py, gloo, world size 2: bit-equal outputs).
+    def fsdp_pre_all_gather(self, mesh, outer_size=None, outer_stride=None, module=None, mp_policy=None):
+        data = self._data
+        if mp_policy is not None and getattr(mp_policy, "param_dtype", None) is not None:
+            data = data.to(mp_policy.param_dtype)
+        return (data,), (self.config,)
+
+    def fsdp_post_all_gather(self, all_gather_outputs, metadata, param_dtype, *, out=None):
+        (data,) = all_gather_outputs
+        (config,) = metadata
+        if out is not None:                      # later all-gathers write into the storage `out._data` already views
+            assert isinstance(out, MixedPrecisionLinearWeight)
+            return
+        return MixedPrecisionLinearWeight(data, config), all_gather_outputs
+
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         if func is F.linear:

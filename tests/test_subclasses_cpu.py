@@ -228,6 +228,77 @@ def test_ddp_gloo_world2_allreduces_int8_mixed_precision_grads():
     assert sorted(results) == [(0, True), (1, True)]
 
 
+# ------------------------------------------------------------------------------- FSDP2 over gloo (llm_pretrain.py:134-139)
+def _fsdp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    sys.path[:0] = [str(root / "quantized-training_amd"), str(root)]
+    import gn_kernels  # noqa: F401
+    import oracle
+    from subclasses import MixedPrecisionLinearWeight, convert_mixed_precision
+    from torch.distributed.fsdp import fully_shard
+
+    impl = torch.library.Library("gn_kernels", "IMPL")
+    impl.impl("scaled_mm", lambda A, B, sa, sb: oracle.scaled_mm(A, B, sa, sb), "CPU")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        model = nn.Sequential(nn.Linear(32, 64, bias=False), nn.GELU(), nn.Linear(64, 32, bias=False)).to(BF)
+        convert_mixed_precision(model)
+        single = copy.deepcopy(model)
+        for m in model:
+            if isinstance(m, nn.Linear):
+                fully_shard(m)
+        fully_shard(model)
+        # the sharded parameter is a DTensor whose local shard is still the wrapper subclass (split / new_zeros / as_strided / copy_
+        # of the dispatch table, reference mixed_precision.py:80-97)
+        local = model[0].weight.to_local()
+        ok = isinstance(local, MixedPrecisionLinearWeight) and local.shape == (64 // world, 32)
+        g = torch.Generator().manual_seed(100)
+        xs = torch.randn(world, 8, 32, generator=g).to(BF)
+        out = model(xs[rank])
+        ok &= torch.equal(out, single(xs[rank]))                 # all-gathered weights are the unsharded ones: same INT8 forward, bit for bit
+        out.float().square().mean().backward()
+        want = None
+        for r in range(world):
+            m = copy.deepcopy(single)
+            m(xs[r]).float().square().mean().backward()
+            grads = [p.grad.float() for p in m.parameters()]
+            want = grads if want is None else [a + b for a, b in zip(want, grads)]
+        for p, w in zip(model.parameters(), want):
+            got = p.grad.full_tensor()
+            got = got._data if hasattr(got, "_data") else got
+            ok &= torch.allclose(got.float(), w / world, atol=2e-2, rtol=2e-2)
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-2)
+        before = model[0].weight.full_tensor()
+        before = (before._data if hasattr(before, "_data") else before).clone()
+        opt.step()
+        after = model[0].weight.full_tensor()
+        after = after._data if hasattr(after, "_data") else after
+        ok &= not torch.equal(before, after) and isinstance(model[0].weight.to_local(), MixedPrecisionLinearWeight)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fsdp2_gloo_world2_shards_int8_mixed_precision_weights():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_fsdp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
+
+
 def test_quantize_model_dispatcher_matches_reference_names():
     """train_utils.quantize_model (reference train_utils.py:35-75): the entry point llm_pretrain.py:122 calls with --quantize / --quantize_kwargs."""
     from train_utils import quantize_model
