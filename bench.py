@@ -193,6 +193,9 @@ def vendor_yardstick(cases, S):
     return out
 
 
+TRAIN_DETAIL_BUDGET_S = 420   # no new training run is started after this many seconds of detail_train
+
+
 def train_detail(world, rank, quick=False):
     """The tok/s half of BASELINE.json's metric, outside the timed region: Llama INT8 mixed-precision training steps through
     train_bench.run (the harness restating llm_pretrain.py), torch.compile(get_loss) as the reference runs it, bf16 beside INT8-MP.
@@ -209,11 +212,20 @@ def train_detail(world, rank, quick=False):
         # form: 16 sequences PER GPU, the per-GPU step of the N = 1 run plus the gradient all-reduce
         runs.append((f"llama-1b weak (global batch {16 * world})", ["--model", "1b", "--batch_size", str(16 * world)], 6, 2, ("mixed_precision",)))
     res = {}
+    t_start = time.perf_counter()
     for name, margs, steps, warm, quants in runs:
         if quick:
             steps, warm = 2, 1
         for q in quants:
             key = f"{name} {'int8_mp' if q == 'mixed_precision' else 'bf16'} compiled"
+            # time budget for the untimed detail (rank 0 decides for everybody, so that no rank enters a collective alone)
+            late = torch.tensor([1.0 if time.perf_counter() - t_start > TRAIN_DETAIL_BUDGET_S else 0.0], device="cuda")
+            if world > 1:
+                dist.broadcast(late, src=0)
+            if late.item() > 0:
+                if rank == 0:
+                    res[key] = f"skipped: detail_train had used its {TRAIN_DETAIL_BUDGET_S} s budget"
+                continue
             try:
                 torch._dynamo.reset()
                 a = train_bench.parse_args(margs + ["--quantize", q, "--steps", str(steps), "--warmup", str(warm), "--compile"])
