@@ -62,6 +62,8 @@ extern "C" int gnk_init(void) {
     return rc;
 }
 
+int gnk_forced_variant_get(void) { return g_forced_variant; }
+
 extern "C" int gnk_set_gemm_variant(int variant) {
     const int old = g_forced_variant;
     g_forced_variant = variant;

@@ -30,6 +30,7 @@ static inline int gnk_debug_flags_get(void) { return 0; }
 #define GNK_DEBUG_BITS(v) 0
 #endif
 int gnk_quantize_noalloc_setup(void);          // gnk_quantize.hip: per-device hipGetSymbolAddress of its scratch array (idempotent)
+int gnk_forced_variant_get(void);          // gnk_api.hip: the calling thread's gnk_set_gemm_variant value (-1: heuristic)
 int gnk_num_cus(void);                         // CU count of the current device (cached)
 
 static inline bool gnk_is_float_dtype(int d) { return d == GNK_BF16 || d == GNK_F16 || d == GNK_F32; }

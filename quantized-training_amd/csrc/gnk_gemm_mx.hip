@@ -22,6 +22,7 @@
 #include "gnk_gemm_dispatch.h"
 
 #include <string.h>
+#include <type_traits>
 
 namespace {
 
@@ -339,6 +340,162 @@ __global__ void __launch_bounds__(512) mxfp4_256_kernel(const MxParams mp) {
     gnk_gemm::run_epilogue<Mx256Cfg>(p, acc, no_accf, smem, wave, lane, mwave, nwave);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// MXFP8, 256 x 256 tile: the 8-phase ping-pong program of gnk_gemm_pp.h (two 128-byte buffers per operand, one
+// v_mfma_scale_f32_16x16x128_f8f6f4 per 16 x 16 tile and K-step) with real scales.  A K-step is 4 MX blocks; the lane that feeds
+// rows r of a 16-row fragment with lane group g supplies the scale byte of block g (header comment), so every fragment read gets ONE
+// ds_read_u8 beside it.  The scale bytes ride the LDS-DMA stream as in mxfp4_256_kernel: a panel is 16 bytes per operand row = four
+// K-steps, lane -> one of the tile's 512 operand rows, issued by every wave in phase 1 of the step before the panel's first step
+// (together with the B half of that tile) and complete at the same vmcnt(0) in phase 5; two panel slots.
+constexpr int MX8_PNL = 512 * 16;
+template <int FA, int FB> struct Mx8Cfg { typedef GemmCfg<256, 256, 2, 4, true, true, OP_F8, FA, FB, EPI_PLAIN> type; };
+constexpr int MX8_256_LDS = Mx8Cfg<0, 0>::type::LDS_BYTES + 2 * MX8_PNL;     // 128 KiB + two 8 KiB scale panels
+
+template <int FA, int FB>
+__global__ void __launch_bounds__(512) mxfp8_256_kernel(const MxParams mp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename Mx8Cfg<FA, FB>::type Cfg;
+    typedef gnk_gemm::PP<Cfg> K;
+    const GemmParams &p = mp.g;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    int tm, tn;
+    gnk_gemm::tile_of_block(p.grid_m, p.grid_n, tm, tn);
+    const int64_t m0 = (int64_t)tm * 256, n0 = (int64_t)tn * 256;
+    char *const Sbuf = smem + Cfg::LDS_BYTES;
+
+    typename K::StA sa;
+    typename K::StB sb;
+    sa.init(p.A, p.lda, m0, p.M, wave, lane);
+    sb.init(p.B, p.ldb, n0, p.N, wave, lane);
+    // scale source of this lane: operand row 64 * wave + lane of the tile's 256 A rows followed by its 256 B rows
+    const unsigned char *ssrc;
+    {
+        const int idx = 64 * wave + lane;
+        int64_t g = idx < 256 ? m0 + idx : n0 + (idx - 256);
+        const int64_t last = (idx < 256 ? p.M : p.N) - 1;
+        g = g < last ? g : last;
+        ssrc = idx < 256 ? mp.sa + g * mp.ldsa : mp.sb + g * mp.ldsb;
+    }
+    auto issue_panel = [&](int u) {                         // scale bytes of K-steps 4 u .. 4 u + 3 -> slot u & 1
+        __builtin_amdgcn_global_load_lds((const GNK_GLOBAL void *)(ssrc + 16 * u), (GNK_LDS void *)(Sbuf + (u & 1) * MX8_PNL + wave * 1024), 16, 0, 0);
+    };
+
+    v4f acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+    v8i fa[4], fb[2];
+    int sca[4], scb[2];
+    const int r = lane & 15, g = lane >> 4;
+    // the lane's scale byte of K-step t for fragment rows `row0 + r` of the panel (A rows 0..255, B rows 256..511): already at byte 0
+    auto scales_a = [&](int t, int qm) {
+        const char *Ss = Sbuf + ((t >> 2) & 1) * MX8_PNL + 4 * (t & 3) + g;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sca[i] = (int)*(const GNK_LDS unsigned char *)(const GNK_LDS char *)(Ss + (wm * 128 + qm * 64 + 16 * i + r) * 16);
+    };
+    auto scales_b = [&](int t, int qn) {
+        const char *Ss = Sbuf + ((t >> 2) & 1) * MX8_PNL + 4 * (t & 3) + g;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) scb[j] = (int)*(const GNK_LDS unsigned char *)(const GNK_LDS char *)(Ss + (256 + wn * 64 + qn * 32 + 16 * j + r) * 16);
+    };
+    auto mfma_q = [&](auto QM, auto QN) {
+        constexpr int qm = decltype(QM)::value, qn = decltype(QN)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)   // matrix B feeds the MFMA's first port (a lane then owns 4 consecutive n of one m): its format code is FB
+                acc[qm * 4 + i][qn * 2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[j], fa[i], acc[qm * 4 + i][qn * 2 + j], FB, FA, 0, scb[j], 0, sca[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(acc[qm * 4 + i][qn * 2 + j]));   // pin the cluster to this phase
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+
+    const int nk = (int)(p.K / GNK_BK);
+    char *const A0 = smem, *const B0 = smem + 2 * Cfg::A_BYTES;
+    // prologue: panel 0 (the oldest load), tile 0 in full and the A half of tile 1, then the first quadrant's fragments
+    issue_panel(0);
+    sa.issue(A0, wave);
+    sb.issue(B0, wave);
+    if (nk > 1) sa.issue(A0 + Cfg::A_BYTES, wave);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    K::template load_a<0>(A0, fa, wm, lane);
+    K::template load_b<0>(B0, fb, wn, lane);
+    scales_a(0, 0);
+    scales_b(0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (wm == 1) __builtin_amdgcn_s_setprio(1);
+    if (wm == 1) __builtin_amdgcn_s_barrier();           // stagger: group 1 runs one phase behind group 0
+    __builtin_amdgcn_sched_barrier(0);
+
+    // The buffer index is a RUN-TIME value on purpose: unrolled by two (compile-time buffers, as gnk_gemm_pp.h does) the kernel keeps both
+    // buffers' fragment and scale addresses live and spills 62 registers (4096^3: 122 us instead of 68-72).
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+        char *const As = smem + buf * Cfg::A_BYTES, *const An = smem + (buf ^ 1) * Cfg::A_BYTES;
+        char *const Bs = B0 + buf * Cfg::B_BYTES, *const Bn = B0 + (buf ^ 1) * Cfg::B_BYTES;
+        mfma_q(I0(), I0());                              // p0
+        K::end_mfma_phase();
+        K::template load_b<1>(Bs, fb, wn, lane);         // p1
+        scales_b(t, 1);
+        if (t + 1 < nk) {
+            if (((t + 1) & 3) == 0) issue_panel((t + 1) >> 2);
+            sb.issue(Bn, wave);
+        }
+        K::end_load_phase();
+        mfma_q(I0(), I1());                              // p2
+        K::end_mfma_phase();
+        K::template load_a<1>(As, fa, wm, lane);         // p3
+        scales_a(t, 1);
+        K::end_load_phase();
+        mfma_q(I1(), I1());                              // p4
+        K::end_mfma_phase();
+        K::template load_b<0>(Bs, fb, wn, lane);         // p5
+        scales_b(t, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); //    this wave's pieces of tile t+1 (and its panel) have landed
+        if (t + 2 < nk) sa.issue(As, wave);
+        K::end_load_phase();
+        mfma_q(I1(), I0());                              // p6
+        K::end_mfma_phase();
+        if (t + 1 < nk) {                                // p7
+            K::template load_a<0>(An, fa, wm, lane);
+            K::template load_b<0>(Bn, fb, wn, lane);
+            scales_a(t + 1, 0);
+            scales_b(t + 1, 0);
+        }
+        K::end_load_phase();
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();           // pay the stagger back so barrier counts match
+    __builtin_amdgcn_sched_barrier(0);
+
+    const int64_t mwave = m0 + wm * 128, nwave = n0 + wn * 64;
+    if (mp.bias) {
+        const int64_t ncol = nwave + 4 * (lane >> 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int64_t n = ncol + 16 * j + q;
+                n = n < p.N ? n : p.N - 1;
+                const float b = gnk_load_scalar_rt(mp.bias, mp.bias_dtype, n);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i][j][q] = __fadd_rn(acc[i][j][q], b);
+            }
+    }
+    __syncthreads();
+    v4f(*no_accf)[1] = nullptr;
+    gnk_gemm::run_epilogue<Cfg>(p, acc, no_accf, smem, wave, lane, mwave, nwave);
+}
+
 // any sizes / alignment (k % 32 == 0 by format): one output per thread, blocks in ascending order
 __global__ void __launch_bounds__(256) mxfp4_generic_kernel(const MxParams mp) {
     const GemmParams &p = mp.g;
@@ -397,17 +554,19 @@ __global__ void __launch_bounds__(256) mxfp8_generic_kernel(const MxParams mp, i
 
 inline bool al(const void *p, int a) { return ((uintptr_t)p % a) == 0; }
 
-template <int FA, int FB> int launch_mxfp8(const MxParams &mp, hipStream_t st) {
-    static bool attr_set[64] = {};
+template <int FA, int FB> int launch_mxfp8(const MxParams &mp, bool big, hipStream_t st) {
+    static bool attr_set[64][2] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return gnk_fail(GNK_ERR_LAUNCH, "mxfp8_mm: no current HIP device");
-    if (!attr_set[dev]) {
-        if (hipFuncSetAttribute((const void *)mx_kernel<4, FA, FB>, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS) != hipSuccess)
-            return gnk_fail(GNK_ERR_LAUNCH, "mxfp8_mm: cannot reserve %d bytes of LDS", MX_LDS);
-        attr_set[dev] = true;
+    if (!attr_set[dev][big]) {
+        const hipError_t e = big ? hipFuncSetAttribute((const void *)mxfp8_256_kernel<FA, FB>, hipFuncAttributeMaxDynamicSharedMemorySize, MX8_256_LDS)
+                                 : hipFuncSetAttribute((const void *)mx_kernel<4, FA, FB>, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS);
+        if (e != hipSuccess) return gnk_fail(GNK_ERR_LAUNCH, "mxfp8_mm: cannot reserve %d bytes of LDS", big ? MX8_256_LDS : MX_LDS);
+        attr_set[dev][big] = true;
     }
-    hipLaunchKernelGGL((mx_kernel<4, FA, FB>), dim3((unsigned)(mp.g.grid_m * mp.g.grid_n)), dim3(256), MX_LDS, st, mp);
-    return gnk_check_launch("mxfp8_mm");
+    if (big) hipLaunchKernelGGL((mxfp8_256_kernel<FA, FB>), dim3((unsigned)(mp.g.grid_m * mp.g.grid_n)), dim3(512), MX8_256_LDS, st, mp);
+    else hipLaunchKernelGGL((mx_kernel<4, FA, FB>), dim3((unsigned)(mp.g.grid_m * mp.g.grid_n)), dim3(256), MX_LDS, st, mp);
+    return gnk_check_launch(big ? "mxfp8_mm (256 x 256)" : "mxfp8_mm");
 }
 
 }  // namespace
@@ -497,12 +656,25 @@ extern "C" int gnk_mxfp8_mm(const void *A, int a_dtype, const void *B, int b_dty
     const bool fast = K >= 256 && K % 256 == 0 && al(A, 16) && al(B, 16) && lda % 16 == 0 && ldb % 16 == 0 && al(scale_A, 8) && al(scale_B, 8) &&
                       ldsa % 8 == 0 && ldsb % 8 == 0 && M < (1LL << 31) && N < (1LL << 31) && lda * 256 < (1LL << 31) && ldb * 256 < (1LL << 31) &&
                       ((M + 127) / 128) * ((N + 127) / 128) < (1LL << 31);
-    if (fast) {
+    // 256 x 256 ping-pong kernel once its tiles fill most of the chip (as plan_gemm does for int8 / fp8); a scale panel is 16 bytes per row
+    // and four K-steps: K % 512 == 0.  gnk_set_gemm_variant: 1 forces the 128 x 128 kernel, 0 / 4 the 256 x 256 one, 2 the generic kernel.
+    const bool fast256 = K >= 512 && K % 512 == 0 && al(A, 16) && al(B, 16) && lda % 16 == 0 && ldb % 16 == 0 && al(scale_A, 16) && al(scale_B, 16) &&
+                         ldsa % 16 == 0 && ldsb % 16 == 0 && M < (1LL << 31) && N < (1LL << 31) && lda * 256 < (1LL << 31) && ldb * 256 < (1LL << 31);
+    const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
+    const int forced = gnk_forced_variant_get();
+    const bool want256 = forced == GNK_VARIANT_256 || forced == GNK_VARIANT_256_PP8 || (forced < 0 && (!fast || tiles256 * 5 >= (int64_t)gnk_num_cus() * 4));
+    const int fa = a_dtype == GNK_E5M2, fb = b_dtype == GNK_E5M2;
+    if (fast256 && tiles256 < (1LL << 31) && want256) {
+        mp.g.grid_m = (int)((M + 255) / 256);
+        mp.g.grid_n = (int)((N + 255) / 256);
+        if (!fa) return fb ? launch_mxfp8<0, 1>(mp, true, st) : launch_mxfp8<0, 0>(mp, true, st);
+        return fb ? launch_mxfp8<1, 1>(mp, true, st) : launch_mxfp8<1, 0>(mp, true, st);
+    }
+    if (fast && forced != GNK_VARIANT_GENERIC) {
         mp.g.grid_m = (int)((M + 127) / 128);
         mp.g.grid_n = (int)((N + 127) / 128);
-        const int fa = a_dtype == GNK_E5M2, fb = b_dtype == GNK_E5M2;
-        if (!fa) return fb ? launch_mxfp8<0, 1>(mp, st) : launch_mxfp8<0, 0>(mp, st);
-        return fb ? launch_mxfp8<1, 1>(mp, st) : launch_mxfp8<1, 0>(mp, st);
+        if (!fa) return fb ? launch_mxfp8<0, 1>(mp, false, st) : launch_mxfp8<0, 0>(mp, false, st);
+        return fb ? launch_mxfp8<1, 1>(mp, false, st) : launch_mxfp8<1, 0>(mp, false, st);
     }
     if (M * N >= (1LL << 31) * 256) return gnk_fail(GNK_ERR_UNSUPPORTED, "mxfp8_mm: output too large for the generic kernel");
     hipLaunchKernelGGL(mxfp8_generic_kernel, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, st, mp, a_dtype == GNK_E5M2, b_dtype == GNK_E5M2);

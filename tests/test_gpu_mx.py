@@ -211,3 +211,65 @@ def test_mxfp8_mm_scale_map_bias_and_end_to_end():
     ref = X.float() @ W.float().T
     rel = (out.float() - ref).norm() / ref.norm()
     assert rel.item() < 0.05, rel.item()          # e4m3 (3 mantissa bits) on Gaussian data: ~3 % relative error
+
+
+# ------------------------------------------------------------------------------------------------ MXFP8, 256 x 256 ping-pong kernel
+class _forced_variant:
+    """gnk_set_gemm_variant around a block: 4 = the 256 x 256 kernel (K % 512 == 0), 1 = the 128 x 128 kernel."""
+
+    def __init__(self, v):
+        from gn_kernels import _cabi
+
+        self.L, self.v = _cabi.load(), v
+
+    def __enter__(self):
+        self.old = self.L.gnk_set_gemm_variant(self.v)
+
+    def __exit__(self, *exc):
+        self.L.gnk_set_gemm_variant(self.old)
+
+
+@pytest.mark.parametrize("fmts", [("e4m3", "e4m3"), ("e5m2", "e4m3"), ("e4m3", "e5m2"), ("e5m2", "e5m2")])
+@pytest.mark.parametrize("shape", [(256, 256, 512), (300, 520, 1024), (512, 256, 2560), (1, 8, 512), (257, 255, 1536)])
+def test_mxfp8_mm_256_kernel_vs_oracle(shape, fmts):
+    """The 8-phase 256 x 256 kernel forced on small and ragged problems: one to five scale panels (a panel = four K-steps), odd and even
+    step counts, rows / columns clamped at the edges; and the same inputs through the 128 x 128 kernel give the same bf16 bits
+    (both kernels accumulate a 16 x 16 tile's K-steps in ascending order with the same instruction)."""
+    M, N, K = shape
+    case = _mx8_case(M, N, K, M * 5 + N + K, *fmts)
+    with _forced_variant(4):
+        big = _check_mm8(*case, *fmts)
+    with _forced_variant(1):
+        small = _check_mm8(*case, *fmts)
+    assert torch.equal(big.view(torch.int16), small.view(torch.int16))
+
+
+def test_mxfp8_mm_256_kernel_scale_map_and_bias():
+    """Every (row, block) scale byte reaches ITS block through the LDS-DMA panel of the 256 x 256 kernel: one scale raised per block, both
+    operands, rows spread over both wave groups and all four wave columns; then bias."""
+    M, N, K = 256, 256, 1024
+    A, Bt, sA, sB = _mx8_case(M, N, K, 6, "e4m3", "e4m3")
+    sA[:], sB[:] = 127, 127
+    with _forced_variant(4):
+        for blk in range(K // 32):
+            sA2, sB2 = sA.clone(), sB.clone()
+            sA2[(37 * blk) % M, blk] = 131
+            sB2[(53 * blk + 7) % N, blk] = 124
+            _check_mm8(A, Bt, sA2, sB2, "e4m3", "e4m3")
+        _check_mm8(A, Bt, sA, sB, "e4m3", "e4m3", bias=torch.randn(N).bfloat16())
+
+
+def test_full_size_4096_mxfp8_auto_dispatch():
+    """4096^3 as bench.py times it (auto dispatch: the 256 x 256 kernel), a sample of rows against the float64 oracle."""
+    M = N = K = 4096
+    A, Bt, sA, sB = _mx8_case(M, N, K, 2026, "e4m3", "e4m3")
+    got = mx.mxfp8_mm(A.to(DEV).view(_F8["e4m3"]), Bt.to(DEV).view(_F8["e4m3"]).T, sA.to(DEV).view(mx.E8M0), sB.to(DEV).view(mx.E8M0))
+    rows = torch.arange(0, M, 131)
+    want = mx_ref.mxfp8_mm(A[rows].numpy(), Bt.numpy(), sA[rows].numpy(), sB.numpy(), "e4m3", "e4m3", None)
+    mag = np.abs(mx_ref.dequantize_mxfp8(A[rows].numpy(), sA[rows].numpy(), "e4m3")) @ np.abs(mx_ref.dequantize_mxfp8(Bt.numpy(), sB.numpy(), "e4m3")).T
+    err = np.abs(got[rows.to(DEV)].float().cpu().numpy().astype(np.float64) - want)
+    bound = 1.6e-2 * np.abs(want) + 5e-5 * mag + 1e-5
+    assert (err <= bound).all(), f"{int((err > bound).sum())} elements outside the tolerance; worst excess {(err - bound).max():.3e}"
+    with _forced_variant(1):
+        small = mx.mxfp8_mm(A.to(DEV).view(_F8["e4m3"]), Bt.to(DEV).view(_F8["e4m3"]).T, sA.to(DEV).view(mx.E8M0), sB.to(DEV).view(mx.E8M0))
+    assert torch.equal(got.view(torch.int16), small.view(torch.int16))
