@@ -390,7 +390,9 @@ __global__ void __launch_bounds__(512) mxfp8_256_kernel(const MxParams mp) {
     v8i fa[4], fb[2];
     int sca[4], scb[2];
     const int r = lane & 15, g = lane >> 4;
-    // the lane's scale byte of K-step t for fragment rows `row0 + r` of the panel (A rows 0..255, B rows 256..511): already at byte 0
+    // the lane's scale byte of K-step t for fragment rows `row0 + r` of the panel (A rows 0..255, B rows 256..511): already at byte 0.
+    // (Reading the K-step's dword of two rows per ds_read2_b32 and shifting by 8 g -- 10 LDS instructions per wave and K-step instead
+    // of 14 -- was 3 % SLOWER; with no scale reads at all the kernel gains 9 %, with no panel traffic 4 %: tools/mx8_ab.py.)
     auto scales_a = [&](int t, int qm) {
         const char *Ss = Sbuf + ((t >> 2) & 1) * MX8_PNL + 4 * (t & 3) + g;
 #pragma unroll
