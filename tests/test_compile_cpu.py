@@ -158,3 +158,26 @@ def test_eager_cache_is_identity_scoped(device_branch_on_cpu):
         t = torch.randn(8, 32, dtype=BF) * 1
         lin(t)
     assert len(mp_mod._cache) == 0
+
+
+@pytest.mark.parametrize("activation", ["none", "int8"])
+def test_compiled_int8_quantized_training_equals_eager(device_branch_on_cpu, activation):
+    """Int8LinearWeight (reference subclasses/int8.py:144-207; llm_finetune.py compiles the model with fullgraph=True): weight-only and
+    dynamic-INT8-activation forwards trace without a graph break and reproduce eager mode bit for bit, gradients included."""
+    from subclasses import Int8QTConfig, convert_int8_quantized_training
+
+    model = _tiny_llama()
+    convert_int8_quantized_training(model.model, config=Int8QTConfig(activation=activation))
+    ref = copy.deepcopy(model)
+    torch.manual_seed(1)
+    tokens = torch.randint(0, 128, (2, 16))
+    labels = torch.randint(0, 128, (2, 16))
+    loss_e = get_loss(ref, tokens, labels)
+    loss_e.backward()
+    loss_c = torch.compile(get_loss, backend="aot_eager", fullgraph=True)(model, tokens, labels)
+    loss_c.backward()
+    assert bits_equal(loss_c.detach(), loss_e.detach())
+    for (n, pe), (_, pc) in zip(ref.named_parameters(), model.named_parameters()):
+        assert (pe.grad is None) == (pc.grad is None), n
+        if pe.grad is not None:
+            assert bits_equal(pc.grad.contiguous(), pe.grad.contiguous()), n

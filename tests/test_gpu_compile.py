@@ -102,3 +102,30 @@ def test_compiled_stochastic_rounding_draws_differ_between_calls_and_steps():
         d = clin(x)
     assert not bits_equal(a, b)
     assert bits_equal(c, d)                           # torch.manual_seed reproduces the draw
+
+
+@pytest.mark.parametrize("activation", ["none", "int8"])
+def test_compiled_int8_quantized_training_linear_matches_eager(activation):
+    """Int8LinearWeight (reference subclasses/int8.py:144-207) under inductor, fullgraph=True: the dynamic-INT8 forward is custom ops only and
+    must equal eager bit for bit; the weight-only forward dequantizes in generated code (bf16 `weight * scale` then matmul), so it is held to
+    the bf16 tolerance of the reference's own check (1e-2)."""
+    from subclasses import Int8QTConfig, convert_int8_quantized_training
+
+    torch.manual_seed(0)
+    lin = nn.Linear(256, 512, bias=False).to(BF).to(DEV)
+    convert_int8_quantized_training(lin, config=Int8QTConfig(activation=activation))
+    ref = copy.deepcopy(lin)
+    x = torch.randn(4, 64, 256, device=DEV, dtype=BF, requires_grad=True)
+    x2 = x.detach().clone().requires_grad_()
+    gy = torch.randn(4, 64, 512, device=DEV, dtype=BF)
+    ref(x2).backward(gy)
+    clin = torch.compile(lin, fullgraph=True)
+    clin(x).backward(gy)
+    with torch.no_grad():
+        out, want = clin(x), ref(x2)
+    if activation == "int8":
+        assert bits_equal(out, want)
+    else:
+        torch.testing.assert_close(out.float(), want.float(), rtol=1e-2, atol=1e-2 * want.float().abs().max().item())
+    torch.testing.assert_close(x.grad.float(), x2.grad.float(), rtol=1e-2, atol=1e-2 * x2.grad.float().abs().max().item())
+    torch.testing.assert_close(lin.weight.grad.float(), ref.weight.grad.float(), rtol=1e-2, atol=1e-2 * ref.weight.grad.float().abs().max().item())
