@@ -22,7 +22,7 @@ def cat(n):
         return "gn_kernels GEMM"
     if "quant_" in n or "col_absmax" in n or "col_quant" in n or "colmax_reduce" in n:
         return "gn_kernels quantize"
-    if "attn" in n.lower() or "fmha" in n.lower() or "flash" in n.lower() or "aotriton" in n.lower():
+    if "attn" in n.lower() or "fmha" in n.lower() or "flash" in n.lower() or "aotriton" in n.lower() or n.startswith("bwd_kernel") or n.startswith("bwd_preprocess"):
         return "attention (SDPA)"
     if n.startswith("Cijk") or "gemm" in n.lower() or "rocblas" in n.lower() or "hipblas" in n.lower():
         return "vendor GEMM (hipBLASLt: lm_head, bf16 Linears)"

@@ -36,11 +36,22 @@ MODELS = {
 }
 
 
-def build_model(name, seq_len, device):
+def build_model(name, seq_len, device, causal_flag=True):
     from transformers import LlamaConfig, LlamaForCausalLM
     from transformers.models.llama.modeling_llama import LlamaRMSNorm
 
     cfg = LlamaConfig(vocab_size=32000, rms_norm_eps=1e-5, max_position_embeddings=seq_len, use_cache=False, **MODELS[name])
+    if causal_flag:
+        # Attention is not part of the scaled-matmul path, but it is 40 % of the step.  While dynamo traces, transformers materialises the
+        # causal mask and calls SDPA with attn_mask=mask, is_causal=False (masking_utils: the is_causal shortcut is skipped under tracing):
+        # 1.95 ms forward / 5.0 ms backward per Llama-1B layer on this stack instead of 0.8 / 2.1 ms with the flag (tools/sdpa_probe.py).
+        # Whole unpadded sequences need no mask tensor: same SDPA function, registered under a name whose mask builder returns None.
+        from transformers import AttentionInterface, AttentionMaskInterface
+        from transformers.integrations.sdpa_attention import sdpa_attention_forward
+
+        AttentionInterface.register("sdpa_causal_flag", sdpa_attention_forward)
+        AttentionMaskInterface.register("sdpa_causal_flag", lambda *a, **k: None)
+        cfg._attn_implementation = "sdpa_causal_flag"
     model = LlamaForCausalLM(cfg)
     for m in model.modules():   # llm_pretrain.py:116-118: RoPE cache stays fp32
         if isinstance(m, (nn.Linear, nn.Embedding, LlamaRMSNorm)):
@@ -72,6 +83,11 @@ def parse_args(argv=None):
     ap.add_argument("--no_fused_quantize", action="store_true", help="A/B: never use the fused row-wise + column-absmax kernels")
     ap.add_argument("--compile", action="store_true", help="loss_fn = torch.compile(get_loss), as llm_pretrain.py:184 (the gn_kernels ops stay opaque nodes)")
     ap.add_argument("--compile_backend", default="inductor", help="torch.compile backend (tests use aot_eager on the CPU)")
+    ap.add_argument("--hf_causal_mask", action="store_true", help="A/B: transformers' default attention call (a materialised causal mask while dynamo traces) "
+                    "instead of SDPA's is_causal flag; same for bf16 and INT8 runs")
+    ap.add_argument("--sdpa", default="default", choices=["default", "flash", "mem_efficient"],
+                    help="SDPA backend of the model's attention (not part of the scaled-matmul path; the same for bf16 and INT8 runs).  On this ROCm stack the "
+                    "flash backend's backward is 2x slower than the memory-efficient one at the Llama-1B shape (tools/sdpa_probe.py: fwd+bwd 4.9 vs 2.9 ms per layer)")
     ap.add_argument("--ddp_bucket_mb", type=int, default=128, help="DDP gradient bucket size.  xGMI is point-to-point (7 links per GPU): RCCL's rings reach their "
                     "per-link rate only on large messages, so the bf16 gradients of a 1B model (2.5 GB) go out as ~20 buckets of 128 MB instead of torch's default "
                     "100 x 25 MB; the first bucket stays 1 MB (torch's default), so the all-reduce still starts with the first gradients of backward")
@@ -95,7 +111,10 @@ def run(args):
     bsize = args.batch_size // world
     torch.manual_seed(1234 + rank)
 
-    model = build_model(args.model, args.seq_len, dev)
+    if on_gpu and args.sdpa != "default":
+        torch.backends.cuda.enable_flash_sdp(args.sdpa == "flash")
+        torch.backends.cuda.enable_mem_efficient_sdp(args.sdpa == "mem_efficient")
+    model = build_model(args.model, args.seq_len, dev, causal_flag=not args.hf_causal_mask)
     if args.activation_checkpointing:
         model.gradient_checkpointing_enable()
     if args.no_quantize_cache or args.no_fused_quantize:
