@@ -261,3 +261,55 @@ def test_loss_curve_matches_the_cpu_restatement_over_50_steps(oracle_cpu_ops):
     assert cpu[-1] < 0.6 * cpu[0], cpu                                   # it learns
     worst = max(abs(a - b) for a, b in zip(cpu, gpu))
     assert worst <= 1e-2, (worst, cpu[::10], gpu[::10])
+
+
+def test_llama1b_sized_linear_all_three_gemms_vs_oracle_samples():
+    """configs[4]'s shapes at their real size: Linear(2048 -> 5632) on 16 x 2048 tokens (the "Llama2-1B" gate / up projection), forward,
+    grad-input and grad-weight through MixedPrecisionLinearWeight (fused quantization plan, 256 x 256 kernels, split-free K = 32768).
+    Witnesses: (1) the same three products recomputed op by op with a DIFFERENT GEMM kernel forced (128 x 128 tiles) are bit-identical over
+    the whole matrices; (2) sampled rows of each product against the CPU oracle fed with the very int8 copies and scales the GPU produced
+    (the quantize kernels have their own full-size tests)."""
+    import gn_kernels
+    import oracle
+    from gn_kernels import _cabi
+    from subclasses import quantize_int8
+
+    T, K, N = 16 * 2048, 2048, 5632
+    torch.manual_seed(7)
+    lin = nn.Linear(K, N, bias=False).to(BF).to(DEV)
+    w = lin.weight.detach().clone()
+    convert_mixed_precision(lin)
+    x = torch.randn(16, 2048, K, device=DEV, dtype=BF, requires_grad=True)
+    gy = torch.randn(16, 2048, N, device=DEV, dtype=BF) * 1e-3
+    y = lin(x)
+    y.backward(gy)
+    dw = lin.weight.grad
+    dw = dw._data if hasattr(dw, "_data") else dw
+    x2, g2 = x.detach().view(T, K), gy.view(T, N)
+
+    L = _cabi.load()
+    old = L.gnk_set_gemm_variant(1)                  # 128 x 128 two-buffer kernel for the recomputation
+    try:
+        xq, xs = quantize_int8(x2, dim=1)
+        wq, ws = quantize_int8(w, dim=1)
+        y_ref = gn_kernels.scaled_mm(xq, wq.T, xs, ws.T)
+        gq, gs = quantize_int8(g2, dim=1)
+        wqc, wsc = quantize_int8(w, dim=0)
+        dx_ref = gn_kernels.scaled_mm(gq, wqc, gs, wsc)
+        xqc, xsc = quantize_int8(x2, dim=0)
+        gqc, gsc = quantize_int8(g2, dim=0)
+        dwt_ref = gn_kernels.scaled_mm(xqc.T, gqc, xsc.T, gsc)        # (K, N) = dW.T
+    finally:
+        L.gnk_set_gemm_variant(old)
+    assert bits_equal(y.view(T, N), y_ref)
+    assert bits_equal(x.grad.view(T, K), dx_ref)
+    assert bits_equal(dw.T.contiguous(), dwt_ref.contiguous())
+
+    rows = torch.arange(5, T, 2731)                  # 12 token rows
+    want = oracle.scaled_mm(xq[rows].cpu(), wq.cpu().T, xs[rows].cpu(), ws.cpu().T)
+    assert bits_equal(y.view(T, N)[rows].cpu(), want)
+    want = oracle.scaled_mm(gq[rows].cpu(), wqc.cpu(), gs[rows].cpu(), wsc.cpu())
+    assert bits_equal(x.grad.view(T, K)[rows].cpu(), want)
+    krows = torch.arange(3, K, 293)                  # 7 rows of dW.T, each a reduction over all 32768 tokens
+    want = oracle.scaled_mm(xqc.T[krows].cpu(), gqc.cpu(), xsc.T[krows].cpu(), gsc.cpu())
+    assert bits_equal(dw.T[krows].cpu().contiguous(), want)
