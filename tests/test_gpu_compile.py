@@ -129,3 +129,51 @@ def test_compiled_int8_quantized_training_linear_matches_eager(activation):
         torch.testing.assert_close(out.float(), want.float(), rtol=1e-2, atol=1e-2 * want.float().abs().max().item())
     torch.testing.assert_close(x.grad.float(), x2.grad.float(), rtol=1e-2, atol=1e-2 * x2.grad.float().abs().max().item())
     torch.testing.assert_close(lin.weight.grad.float(), ref.weight.grad.float(), rtol=1e-2, atol=1e-2 * ref.weight.grad.float().abs().max().item())
+
+
+def test_ddp_over_rccl_with_compiled_loss_single_rank():
+    """The configuration bench.py's detail_train runs at N > 1 (train_bench.run: DDP with 128 MB buckets as gradient views around the
+    converted model, torch.compile(get_loss), fused AdamW), on the one GPU of this box: a one-rank RCCL group.  Two steps; the losses
+    equal those of the same model trained without DDP (same compiled graph, the all-reduce of one rank is the identity)."""
+    import os
+    import sys
+    from pathlib import Path
+
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import train_bench
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29900 + os.getpid() % 100))
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        torch.manual_seed(5)
+        base = train_bench.build_model("tiny", 128, torch.device(DEV))
+        convert_mixed_precision(base.model)
+        tokens = torch.randint(0, 32000, (4, 128), device=DEV)
+        labels = torch.randint(0, 32000, (4, 128), device=DEV)
+        losses = {}
+        for name in ("plain", "ddp"):
+            torch._dynamo.reset()
+            model = copy.deepcopy(base)
+            if name == "ddp":
+                model = DDP(model, device_ids=[0], bucket_cap_mb=128, gradient_as_bucket_view=True)
+            opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)
+            loss_fn = torch.compile(train_bench.get_loss)
+            out = []
+            for _ in range(2):
+                loss = loss_fn(model, tokens, labels)
+                loss.backward()
+                opt.step()
+                opt.zero_grad()
+                out.append(loss.item())
+            losses[name] = out
+        assert losses["ddp"][0] == losses["plain"][0]
+        assert abs(losses["ddp"][1] - losses["plain"][1]) <= 1e-2 and losses["ddp"][1] < losses["ddp"][0] + 1e-2
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -313,3 +313,43 @@ def test_llama1b_sized_linear_all_three_gemms_vs_oracle_samples():
     krows = torch.arange(3, K, 293)                  # 7 rows of dW.T, each a reduction over all 32768 tokens
     want = oracle.scaled_mm(xqc.T[krows].cpu(), gqc.cpu(), xsc.T[krows].cpu(), gsc.cpu())
     assert bits_equal(dw.T[krows].cpu().contiguous(), want)
+
+
+def test_fsdp2_on_the_gpu_keeps_the_int8_path_single_rank_rccl():
+    """fully_shard over RCCL (one rank: the box has one GPU) with MixedPrecisionLinearWeight's all-gather hooks: the unsharded weight the
+    forward sees is still the wrapper, so outputs and gradients equal the unsharded model's bit for bit (without the hooks FSDP2 hands
+    F.linear a plain bf16 tensor and the comparison fails by bf16 rounding)."""
+    import os
+
+    import torch.distributed as dist
+    from torch.distributed.fsdp import fully_shard
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29800 + os.getpid() % 100))
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        torch.manual_seed(3)
+        model = nn.Sequential(nn.Linear(256, 512, bias=False), nn.GELU(), nn.Linear(512, 256, bias=False)).to(BF).to(DEV)
+        convert_mixed_precision(model)
+        single = copy.deepcopy(model)
+        for m in model:
+            if isinstance(m, nn.Linear):
+                fully_shard(m)
+        fully_shard(model)
+        assert isinstance(model[0].weight.to_local(), MixedPrecisionLinearWeight)
+        x = torch.randn(64, 256, device=DEV, dtype=BF)
+        out = model(x)
+        ref = single(x)
+        assert bits_equal(out, ref)
+        out.float().square().mean().backward()
+        ref.float().square().mean().backward()
+        for p, q in zip(model.parameters(), single.parameters()):
+            g = p.grad.full_tensor()
+            g = g._data if hasattr(g, "_data") else g
+            h = q.grad._data if hasattr(q.grad, "_data") else q.grad
+            assert bits_equal(g.contiguous(), h.contiguous())
+    finally:
+        if created:
+            dist.destroy_process_group()
