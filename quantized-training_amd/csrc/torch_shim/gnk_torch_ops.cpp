@@ -73,6 +73,11 @@ at::Tensor scaled_mm(const at::Tensor &A, const at::Tensor &B, const at::Tensor 
     return scaled_mm_impl(A, B, rs, cs, rs.scalar_type(), 0, "scaled_mm");
 }
 
+// == scaled_mm(A, B, sA, sB).T as a contiguous tensor (gn_kernels/mm.py:scaled_mm_t): operand roles and multiply order swapped together
+at::Tensor scaled_mm_t(const at::Tensor &A, const at::Tensor &B, const at::Tensor &sA, const at::Tensor &sB) {
+    return scaled_mm_impl(B.t(), A.t(), sB, sA, sA.scalar_type(), 1, "scaled_mm_t");
+}
+
 // block sizes from integer shape ratios (reference triton_mm.py:419,434-436); ragged tilings are refused (see gn_kernels/mm.py)
 at::Tensor tile_scaled_mm(const at::Tensor &A, const at::Tensor &B, const at::Tensor &sA, const at::Tensor &sB) {
     const int64_t M = A.size(0), K = A.size(1), N = B.size(1);
@@ -192,6 +197,7 @@ std::tuple<at::Tensor, at::Tensor> quantize_int8_colwise_given(const at::Tensor 
 TORCH_LIBRARY_IMPL(gn_kernels, CUDA, m) {
     m.impl("int8_mm", &int8_mm);
     m.impl("scaled_mm", &scaled_mm);
+    m.impl("scaled_mm_t", &scaled_mm_t);
     m.impl("tile_scaled_mm", &tile_scaled_mm);
     m.impl("quantize_int8", &quantize_int8);
     m.impl("quantize_int8_rowwise_colmax", &quantize_int8_rowwise_colmax);

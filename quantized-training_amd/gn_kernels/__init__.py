@@ -5,7 +5,7 @@ NotImplementedError when called."""
 from . import _cabi
 from . import bitnet  # noqa: F401  (registers the bitnet_* device ops)
 from .fp8 import fp8_mm, scaled_fp8_mm
-from .mm import _triton_mm, int8_mm, scaled_mm
+from .mm import _triton_mm, int8_mm, scaled_mm, scaled_mm_t
 from .mx import dequantize_mxfp4, mxfp4_mm, mxfp8_mm, pack_block_scales_nv, quantize_mx
 from .quantize import quantize_int8
 
@@ -41,6 +41,7 @@ __all__ = [
     "_triton_mm",
     "int8_mm",
     "scaled_mm",
+    "scaled_mm_t",
     "quantize_int8",
     "quantize_mx",
     "quantize_nvfp4",

@@ -30,7 +30,7 @@ _lib = None
 # Same kernels, same C ABI; only the per-call host path changes (dispatcher -> C++ -> C ABI instead of dispatcher -> Python -> ctypes).
 # GNK_NO_TORCH_SHIM=1 keeps the Python implementations (A/B timing of the host path, and the tests' second leg).
 _SHIM_PATH = Path(__file__).resolve().parent / "libgnk_torch_ops.so"
-_SHIM_OPS = ("int8_mm", "scaled_mm", "tile_scaled_mm", "quantize_int8", "quantize_int8_rowwise_colmax", "quantize_int8_colwise_given")
+_SHIM_OPS = ("int8_mm", "scaled_mm", "scaled_mm_t", "tile_scaled_mm", "quantize_int8", "quantize_int8_rowwise_colmax", "quantize_int8_colwise_given")
 _shim_loaded = None
 
 

@@ -25,7 +25,7 @@ import torch.utils._pytree as pytree
 from torch import Tensor, nn
 
 from gn_kernels import quantize as _qop
-from gn_kernels import scaled_mm
+from gn_kernels import scaled_mm, scaled_mm_t
 
 from .int8 import quantize_int8
 
@@ -311,7 +311,9 @@ class _Int8MixedPrecisionLinear(torch.autograd.Function):
             if cfg.grad_weight and plan:
                 xq, xs = _q_cols(x2d, sr, x_cm, input)           # == quantize_int8(x2d.T, dim=1), transposed
                 gq0, gs0 = _q_cols(go2d, sr, g_cm)
-                grad_weight = scaled_mm(xq.T, gq0, xs.T, gs0).T                                    # (A.T @ B).T
+                # reference :184-186 `_dynamic_mm(input.T, grad_output).T`: the same numbers, written straight into the weight's (N, K)
+                # layout instead of a transposed view that AccumulateGrad would copy (gn_kernels/mm.py:scaled_mm_t)
+                grad_weight = scaled_mm_t(xq.T, gq0, xs.T, gs0)                                    # (A.T @ B).T, contiguous
             elif cfg.grad_weight:
                 grad_weight = _dynamic_mm(x2d.T, go2d, sr, cfg.dtype).T
             else:

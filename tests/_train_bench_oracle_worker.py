@@ -22,6 +22,7 @@ def _sr(sr, rng):
 
 
 impl.impl("scaled_mm", lambda A, B, sa, sb: oracle.scaled_mm(A, B, sa, sb), "CPU")
+impl.impl("scaled_mm_t", lambda A, B, sa, sb: oracle.scaled_mm(A, B, sa, sb).T.contiguous(), "CPU")
 impl.impl("quantize_int8", lambda x, dim, sr, eps, rng=None: oracle.quantize_int8(x, sr, dim=dim, eps=eps, **_sr(sr, rng)), "CPU")
 impl.impl("quantize_int8_rowwise_colmax",
           lambda x, sr, eps, rng=None: (*oracle.quantize_int8(x, sr, dim=1, eps=eps, **_sr(sr, rng)), x.float().abs().amax(0)), "CPU")

@@ -58,6 +58,7 @@ def oracle_cpu_ops():
         return oracle.quantize_int8(x, sr, dim=0, eps=eps, **_sr(sr, rng))
 
     impl.impl("scaled_mm", scaled_mm_cpu, "CPU")
+    impl.impl("scaled_mm_t", lambda A, B, sa, sb: oracle.scaled_mm(A, B, sa, sb).T.contiguous(), "CPU")   # its definition: the transpose, materialised
     impl.impl("tile_scaled_mm", scaled_mm_cpu, "CPU")
     impl.impl("int8_mm", int8_mm_cpu, "CPU")
     impl.impl("quantize_int8", quantize_cpu, "CPU")

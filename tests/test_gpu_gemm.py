@@ -547,3 +547,29 @@ def test_k_tails_run_on_the_mfma_kernel_bit_exact(K, layout):
     # the heuristic must take an MFMA kernel too (same bits), not the generic fallback: compare, and for the big K time-box it
     out = gn_kernels.scaled_mm(Ad, Bd, rs.to(DEV), cs.to(DEV))
     assert bits_equal(out, oracle.scaled_mm(A, B, rs, cs))
+
+
+@pytest.mark.parametrize("shape", [(256, 512, 1024), (1000, 330, 2048), (64, 48, 4100), (2048, 2048, 8192), (1, 7, 64)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_scaled_mm_t_is_the_materialised_transpose(shape, dt):
+    """gn_kernels.scaled_mm_t (the grad-weight form of subclasses/mixed_precision.py): bit-identical to scaled_mm(...).T.contiguous() --
+    the operand swap comes with the epilogue's multiply order swapped, so each element is still (acc * scale_A[m]) * scale_B[n] -- in the
+    grad-weight layout (A = X.T, both operands M/N-major), with K-major operands, with ragged sizes, a K tail and a split-K shape."""
+    import gn_kernels
+
+    M, N, K = shape
+    torch.manual_seed(M + N + K)
+    sa = (torch.rand(M, 1, device=DEV) * 0.02 + 1e-3).to(dt)
+    sb = (torch.rand(1, N, device=DEV) * 0.02 + 1e-3).to(dt)
+    At = torch.randint(-128, 128, (K, M), dtype=torch.int8, device=DEV)          # A = At.T: M-major, as X.T in the Linear backward
+    B = torch.randint(-128, 128, (K, N), dtype=torch.int8, device=DEV)
+    for A in (At.T, At.T.contiguous()):
+        want = gn_kernels.scaled_mm(A, B, sa, sb).T.contiguous()
+        got = gn_kernels.scaled_mm_t(A, B, sa, sb)
+        assert got.shape == (N, M) and got.is_contiguous() and got.dtype is dt
+        assert torch.equal(got.view(torch.int16 if dt is torch.bfloat16 else torch.int32), want.view(torch.int16 if dt is torch.bfloat16 else torch.int32))
+    a8 = torch.randn(M, K, device=DEV).to(torch.float8_e4m3fn)
+    b8 = torch.randn(N, K, device=DEV).to(torch.float8_e4m3fn).T
+    want = gn_kernels.scaled_mm(a8, b8, sa, sb).T.contiguous()
+    got = gn_kernels.scaled_mm_t(a8, b8, sa, sb)
+    torch.testing.assert_close(got.float(), want.float(), rtol=1.6e-2, atol=1e-5 + 5e-5 * float((a8.float().abs() @ b8.float().abs()).max() * sa.float().max() * sb.float().max()))
