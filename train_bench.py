@@ -36,20 +36,35 @@ MODELS = {
 }
 
 
-def build_model(name, seq_len, device, causal_flag=True):
+def build_model(name, seq_len, device, causal_flag=True, sdpa="mem_efficient"):
     from transformers import LlamaConfig, LlamaForCausalLM
     from transformers.models.llama.modeling_llama import LlamaRMSNorm
 
     cfg = LlamaConfig(vocab_size=32000, rms_norm_eps=1e-5, max_position_embeddings=seq_len, use_cache=False, **MODELS[name])
     if causal_flag:
-        # Attention is not part of the scaled-matmul path, but it is 40 % of the step.  While dynamo traces, transformers materialises the
-        # causal mask and calls SDPA with attn_mask=mask, is_causal=False (masking_utils: the is_causal shortcut is skipped under tracing):
-        # 1.95 ms forward / 5.0 ms backward per Llama-1B layer on this stack instead of 0.8 / 2.1 ms with the flag (tools/sdpa_probe.py).
-        # Whole unpadded sequences need no mask tensor: same SDPA function, registered under a name whose mask builder returns None.
+        # Attention is not part of the scaled-matmul path, but it was 40 % of the compiled step as the reference's harness builds it:
+        #  * while dynamo traces, transformers materialises the causal mask and calls SDPA with attn_mask=mask, is_causal=False
+        #    (masking_utils: the is_causal shortcut is skipped under tracing): 1.95 ms forward / 5.0 ms backward per Llama-1B layer on
+        #    this stack instead of 0.8 / 4.0 ms with the flag.  Whole unpadded sequences need no mask tensor: same SDPA function,
+        #    registered under a name whose mask builder returns None;
+        #  * the compiled graph always takes SDPA's flash backend, whose backward (aotriton) is 1.7x slower here than the
+        #    memory-efficient backend's (tools/sdpa_probe2.py: fwd+bwd 4.75 vs 2.75 ms per layer, identical outputs; the global
+        #    enable_*_sdp switches are not consulted while tracing, a `sdpa_kernel` context inside the traced function is).
+        # Same setting for bf16 and INT8 runs.
+        from torch.nn.attention import SDPBackend, sdpa_kernel
         from transformers import AttentionInterface, AttentionMaskInterface
         from transformers.integrations.sdpa_attention import sdpa_attention_forward
 
-        AttentionInterface.register("sdpa_causal_flag", sdpa_attention_forward)
+        on_gpu = torch.device(device).type == "cuda"
+        backend = {"mem_efficient": SDPBackend.EFFICIENT_ATTENTION, "flash": SDPBackend.FLASH_ATTENTION}.get(sdpa) if on_gpu else None
+
+        def sdpa_causal_flag(module, query, key, value, attention_mask, **kwargs):
+            if backend is None:
+                return sdpa_attention_forward(module, query, key, value, None, **kwargs)
+            with sdpa_kernel(backend):
+                return sdpa_attention_forward(module, query, key, value, None, **kwargs)
+
+        AttentionInterface.register("sdpa_causal_flag", sdpa_causal_flag)
         AttentionMaskInterface.register("sdpa_causal_flag", lambda *a, **k: None)
         cfg._attn_implementation = "sdpa_causal_flag"
     model = LlamaForCausalLM(cfg)
@@ -85,9 +100,9 @@ def parse_args(argv=None):
     ap.add_argument("--compile_backend", default="inductor", help="torch.compile backend (tests use aot_eager on the CPU)")
     ap.add_argument("--hf_causal_mask", action="store_true", help="A/B: transformers' default attention call (a materialised causal mask while dynamo traces) "
                     "instead of SDPA's is_causal flag; same for bf16 and INT8 runs")
-    ap.add_argument("--sdpa", default="default", choices=["default", "flash", "mem_efficient"],
-                    help="SDPA backend of the model's attention (not part of the scaled-matmul path; the same for bf16 and INT8 runs).  On this ROCm stack the "
-                    "flash backend's backward is 2x slower than the memory-efficient one at the Llama-1B shape (tools/sdpa_probe.py: fwd+bwd 4.9 vs 2.9 ms per layer)")
+    ap.add_argument("--sdpa", default="mem_efficient", choices=["default", "flash", "mem_efficient"],
+                    help="SDPA backend of the model's attention on the GPU (not part of the scaled-matmul path; the same for bf16 and INT8 runs): "
+                    "see build_model")
     ap.add_argument("--ddp_bucket_mb", type=int, default=128, help="DDP gradient bucket size.  xGMI is point-to-point (7 links per GPU): RCCL's rings reach their "
                     "per-link rate only on large messages, so the bf16 gradients of a 1B model (2.5 GB) go out as ~20 buckets of 128 MB instead of torch's default "
                     "100 x 25 MB; the first bucket stays 1 MB (torch's default), so the all-reduce still starts with the first gradients of backward")
@@ -111,10 +126,7 @@ def run(args):
     bsize = args.batch_size // world
     torch.manual_seed(1234 + rank)
 
-    if on_gpu and args.sdpa != "default":
-        torch.backends.cuda.enable_flash_sdp(args.sdpa == "flash")
-        torch.backends.cuda.enable_mem_efficient_sdp(args.sdpa == "mem_efficient")
-    model = build_model(args.model, args.seq_len, dev, causal_flag=not args.hf_causal_mask)
+    model = build_model(args.model, args.seq_len, dev, causal_flag=not args.hf_causal_mask, sdpa=args.sdpa)
     if args.activation_checkpointing:
         model.gradient_checkpointing_enable()
     if args.no_quantize_cache or args.no_fused_quantize:
