@@ -64,9 +64,10 @@ def build_model(name, seq_len, device, causal_flag=True, sdpa="mem_efficient"):
             with sdpa_kernel(backend):
                 return sdpa_attention_forward(module, query, key, value, None, **kwargs)
 
-        AttentionInterface.register("sdpa_causal_flag", sdpa_causal_flag)
-        AttentionMaskInterface.register("sdpa_causal_flag", lambda *a, **k: None)
-        cfg._attn_implementation = "sdpa_causal_flag"
+        impl = f"sdpa_causal_flag_{sdpa if backend is not None else 'any'}"      # one registry entry per backend choice
+        AttentionInterface.register(impl, sdpa_causal_flag)
+        AttentionMaskInterface.register(impl, lambda *a, **k: None)
+        cfg._attn_implementation = impl
     model = LlamaForCausalLM(cfg)
     for m in model.modules():   # llm_pretrain.py:116-118: RoPE cache stays fp32
         if isinstance(m, (nn.Linear, nn.Embedding, LlamaRMSNorm)):
