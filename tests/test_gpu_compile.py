@@ -146,7 +146,7 @@ def test_ddp_over_rccl_with_compiled_loss_single_rank():
     import train_bench
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", str(29900 + os.getpid() % 100))
+    os.environ["MASTER_PORT"] = str(29900 + os.getpid() % 100)        # its own port: another test of this process may have used the default
     created = not dist.is_initialized()
     if created:
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))

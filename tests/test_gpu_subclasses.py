@@ -325,7 +325,7 @@ def test_fsdp2_on_the_gpu_keeps_the_int8_path_single_rank_rccl():
     from torch.distributed.fsdp import fully_shard
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", str(29800 + os.getpid() % 100))
+    os.environ["MASTER_PORT"] = str(29800 + os.getpid() % 100)        # its own port: another test of this process may have used the default
     created = not dist.is_initialized()
     if created:
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
