@@ -18,6 +18,7 @@ template <int OP, int FA, int FB>
 __global__ void __launch_bounds__(256) gemm_generic_kernel(const GenericParams p) {
     __shared__ __attribute__((aligned(16))) char As[GB * GP];
     __shared__ __attribute__((aligned(16))) char Bs[GB * GP];
+    __shared__ float sAs[GB], sBs[GB];        // tile scales of the current K-block: rows m0 .. m0 + 63, columns n0 .. n0 + 63
     typedef typename gnk_gemm::AccT<OP>::type acc_t;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -27,6 +28,9 @@ __global__ void __launch_bounds__(256) gemm_generic_kernel(const GenericParams p
     // loader role: row lr of the tile, 8 consecutive k starting at lk
     const int lr = threadIdx.x >> 2, lk = (threadIdx.x & 3) * 8;
     const int64_t am = m0 + lr, bn = n0 + lr;
+    // loader role for an operand whose M / N dim is the contiguous one: k = ck of the chunk, 8 consecutive rows starting at cr
+    const int ck = threadIdx.x >> 3, cr = (threadIdx.x & 7) * 8;
+    const bool a_rowc = p.sam == 1 && p.sak != 1, b_rowc = p.sbn == 1 && p.sbk != 1;
 
     acc_t part[2][2];
     v4f accf[2][2];
@@ -45,19 +49,81 @@ __global__ void __launch_bounds__(256) gemm_generic_kernel(const GenericParams p
     for (int64_t kb0 = 0, kb = 0; kb0 < p.K; kb0 += QK, ++kb) {
         const int64_t kend = kb0 + QK < p.K ? kb0 + QK : p.K;
         for (int64_t k0 = kb0; k0 < kend; k0 += GK) {
-            // gather 8 bytes of A[am, k0+lk ..] and B[k0+lk .., bn]
+            // Gather the chunk (64 rows x 32 k per operand) into the K-major LDS images.  An operand whose K dim is contiguous is read as
+            // 8 consecutive k of one row per thread; one whose M / N dim is contiguous as 8 consecutive rows of one k per thread (coalesced
+            // along the contiguous dim, scattered into 8 LDS rows); either way ONE 8-byte load when the group is whole, in bounds and 8-byte
+            // aligned, else element by element (bounds-checked, zero filled) -- which is also the path of doubly strided operands.
+            // (The first version read every operand byte by byte: 22 TOP/s at 4096^3.)
             unsigned long long pa = 0, pb = 0;
+            const int64_t kk = k0 + lk;              // K-contiguous role: row lr, k = kk .. kk + 7
+            const int64_t kc = k0 + ck;              // row-contiguous role: k = kc, rows cr .. cr + 7
+            if (a_rowc) {
+                const int64_t m = m0 + cr;
+                const char *src = p.A + m * p.sam + kc * p.sak;
+                if (kc < kend) {
+                    if (m + 8 <= p.M && ((uintptr_t)src & 7) == 0) pa = *(const unsigned long long *)src;
+                    else
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int64_t k = k0 + lk + e;
-                if (k < kend) {
-                    if (am < p.M) pa |= (unsigned long long)(unsigned char)p.A[am * p.sam + k * p.sak] << (8 * e);
-                    if (bn < p.N) pb |= (unsigned long long)(unsigned char)p.B[k * p.sbk + bn * p.sbn] << (8 * e);
+                        for (int e = 0; e < 8; ++e)
+                            if (m + e < p.M) pa |= (unsigned long long)(unsigned char)src[e] << (8 * e);
+                }
+            } else {
+                const char *src = p.A + am * p.sam + kk * p.sak;
+                if (am < p.M) {
+                    if (p.sak == 1 && kk + 8 <= kend && ((uintptr_t)src & 7) == 0) pa = *(const unsigned long long *)src;
+                    else
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (kk + e < kend) pa |= (unsigned long long)(unsigned char)src[e * p.sak] << (8 * e);
                 }
             }
-            __syncthreads();   // previous chunk's fragments have been read
-            *(unsigned long long *)(As + lr * GP + lk) = pa;
-            *(unsigned long long *)(Bs + lr * GP + lk) = pb;
+            if (b_rowc) {
+                const int64_t n = n0 + cr;
+                const char *src = p.B + kc * p.sbk + n * p.sbn;
+                if (kc < kend) {
+                    if (n + 8 <= p.N && ((uintptr_t)src & 7) == 0) pb = *(const unsigned long long *)src;
+                    else
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (n + e < p.N) pb |= (unsigned long long)(unsigned char)src[e] << (8 * e);
+                }
+            } else {
+                const char *src = p.B + kk * p.sbk + bn * p.sbn;
+                if (bn < p.N) {
+                    if (p.sbk == 1 && kk + 8 <= kend && ((uintptr_t)src & 7) == 0) pb = *(const unsigned long long *)src;
+                    else
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (kk + e < kend) pb |= (unsigned long long)(unsigned char)src[e * p.sbk] << (8 * e);
+                }
+            }
+            __syncthreads();   // previous chunk's fragments (and the previous K-block's scales) have been read
+            if (p.epi == EPI_TILE && k0 == kb0 && threadIdx.x < 2 * GB) {
+                // this K-block's scales, one per thread (per-lane loads in the rescale, 10 dependent global loads per block and lane,
+                // held the tile-scaled fallback at 16 TOP/s for 16-k blocks)
+                const int t = threadIdx.x & (GB - 1);
+                if (threadIdx.x < GB) {
+                    int64_t m = m0 + t;
+                    m = m < p.M ? m : p.M - 1;
+                    sAs[t] = gnk_load_scalar_rt(p.s0, p.scale_dtype, (m / p.QM) * p.ssam + kb * p.ssak);
+                } else {
+                    int64_t n = n0 + t;
+                    n = n < p.N ? n : p.N - 1;
+                    sBs[t] = gnk_load_scalar_rt(p.s1, p.scale_dtype, kb * p.ssbk + (n / p.QN) * p.ssbn);
+                }
+            }
+            if (a_rowc) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) As[(cr + e) * GP + ck] = (char)(pa >> (8 * e));
+            } else {
+                *(unsigned long long *)(As + lr * GP + lk) = pa;
+            }
+            if (b_rowc) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) Bs[(cr + e) * GP + ck] = (char)(pb >> (8 * e));
+            } else {
+                *(unsigned long long *)(Bs + lr * GP + lk) = pb;
+            }
             __syncthreads();
             long fa[2], fb[2];
 #pragma unroll
@@ -80,16 +146,12 @@ __global__ void __launch_bounds__(256) gemm_generic_kernel(const GenericParams p
             // acc_f32 += (f32(partial) * sA[m/QM, kb]) * sB[kb, n/QN], separate roundings (triton_mm.py:327-331)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                int64_t m = mrow + 16 * i;
-                m = m < p.M ? m : p.M - 1;
-                const float sa = gnk_load_scalar_rt(p.s0, p.scale_dtype, (m / p.QM) * p.ssam + kb * p.ssak);
+                const float sa = sAs[wm * 32 + 16 * i + (lane & 15)];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        int64_t n = ncol + 16 * j + r;
-                        n = n < p.N ? n : p.N - 1;
-                        const float sb = gnk_load_scalar_rt(p.s1, p.scale_dtype, kb * p.ssbk + (n / p.QN) * p.ssbn);
+                        const float sb = sBs[wn * 32 + 4 * (lane >> 4) + 16 * j + r];
                         float a;
                         if constexpr (OP == OP_I8) a = (float)part[i][j][r];
                         else a = part[i][j][r];
