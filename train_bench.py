@@ -99,6 +99,8 @@ def parse_args(argv=None):
     ap.add_argument("--no_fused_quantize", action="store_true", help="A/B: never use the fused row-wise + column-absmax kernels")
     ap.add_argument("--compile", action="store_true", help="loss_fn = torch.compile(get_loss), as llm_pretrain.py:184 (the gn_kernels ops stay opaque nodes)")
     ap.add_argument("--compile_backend", default="inductor", help="torch.compile backend (tests use aot_eager on the CPU)")
+    ap.add_argument("--compile_mode", default=None, help='torch.compile mode, e.g. "reduce-overhead" (forward and backward replayed as HIP graphs: the gn_kernels ops '
+                    "allocate through torch's caching allocator and launch on the current stream, so they capture)")
     ap.add_argument("--hf_causal_mask", action="store_true", help="A/B: transformers' default attention call (a materialised causal mask while dynamo traces) "
                     "instead of SDPA's is_causal flag; same for bf16 and INT8 runs")
     ap.add_argument("--sdpa", default="mem_efficient", choices=["default", "flash", "mem_efficient"],
@@ -171,7 +173,7 @@ def run(args):
                 t[:, i] = torch.where(keep[:, i], perm[t[:, i - 1]], noise[:, i])
         return t[:, :-1].contiguous(), t[:, 1:].contiguous()
 
-    loss_fn = torch.compile(get_loss, backend=args.compile_backend) if args.compile else get_loss     # llm_pretrain.py:184
+    loss_fn = torch.compile(get_loss, backend=args.compile_backend, mode=args.compile_mode) if args.compile else get_loss     # llm_pretrain.py:184
 
     def step():
         tokens, labels = batch()
