@@ -147,6 +147,14 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, bool can256, bool can128, bo
         const double tiles = (double)(((M + 255) / 256) * ((N + 255) / 256));
         const double t = ceil(tiles / cus) * (15.0 + 1.4 * ksteps);
         if (t < best_t) { best_t = t; best = {GNK_VARIANT_256, 1}; }
+        // round 2: split-K on the four-stage 256 x 256 kernel too (grad-weights of square Linears, 2048 x 2048 x 32768: 64 tiles)
+        if (can_split && K >= 8192) {
+            for (int sp = 2; sp <= 8; sp *= 2) {
+                if (K / sp < 2048) break;
+                const double ts = ceil(tiles * sp / cus) * (15.0 + 1.4 * ksteps / sp) + 6.0 + (double)sp * (double)M * (double)N * 8.0 / 4.0e6;
+                if (ts < best_t) { best_t = ts; best = {GNK_VARIANT_256, sp}; }
+            }
+        }
     }
     if (can128) {
         const double tiles = (double)(((M + 127) / 128) * ((N + 127) / 128));
@@ -246,7 +254,7 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
         // A K-major (A@B.T, A@B): the 8-phase kernel.  Measured at 4096^3 against the 4-stage one (tools/cmp_variants.py, round 2): int8
         // A@B.T 54.0 vs 59.4 us, A@B 56.2 vs 57.5; fp8 (one 16x16x128 MFMA per tile and step instead of two 32x32x64) A@B.T 52.2 vs 59.4,
         // A@B 54.1 vs 55.7.  A M-major (A.T@B) stays on the 4-stage kernel (fp8 55.3 vs 57.9, int8 level).
-        if (variant == GNK_VARIANT_256 && la.kmajor && ok_128 && whole_steps) variant = GNK_VARIANT_256_PP8;
+        if (variant == GNK_VARIANT_256 && splits == 1 && la.kmajor && ok_128 && whole_steps) variant = GNK_VARIANT_256_PP8;
     } else if (variant != GNK_VARIANT_GENERIC &&
                !(variant == GNK_VARIANT_256 ? ok_pp2 : variant == GNK_VARIANT_128 ? ok_128 : (ok_128 && whole_steps))) {
         return gnk_fail(GNK_ERR_UNSUPPORTED, "%s: forced fast variant %d cannot take these strides / sizes", name, variant);
@@ -270,7 +278,7 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
             p.A = (const char *)c.A; p.B = (const char *)c.B; p.C = c.ws;
             p.M = c.M; p.N = c.N; p.K = c.K; p.lda = la.ld; p.ldb = lb.ld; p.out_dtype = GNK_I32;
             p.kchunk = ((c.K / GNK_BK + splits - 1) / splits) * GNK_BK;
-            rc = gnk_launch_i8_v1(la.kmajor, lb.kmajor, EPI_PLAIN, p, st);
+            rc = variant == GNK_VARIANT_256 ? gnk_launch_i8_v0(la.kmajor, lb.kmajor, EPI_PLAIN, p, st) : gnk_launch_i8_v1(la.kmajor, lb.kmajor, EPI_PLAIN, p, st);
             if (rc) return rc;
             const int nsplit = (int)((c.K + p.kchunk - 1) / p.kchunk);
             const unsigned blocks = (unsigned)((c.M * c.N / 4 + 255) / 256);

@@ -292,9 +292,23 @@ template <class Cfg> struct PP2Select<Cfg, OP_I8> { typedef PP2I8<Cfg> type; };
 template <class Cfg> struct PP2Select<Cfg, OP_F8> { typedef PP2F8<Cfg> type; };
 
 template <class Cfg>
-__global__ void __launch_bounds__(512) gemm_pp2_kernel(const GemmParams p) {
+__global__ void __launch_bounds__(512) gemm_pp2_kernel(const GemmParams p_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename PP2Select<Cfg, Cfg::OP>::type K;
+
+    // split-K (plain int32 output only), as in gemm_kernel: split s = blockIdx.y covers k in [s * kchunk, min(K, (s + 1) * kchunk)) and owns
+    // slab s of the workspace; integer partial sums add exactly.  Wave-uniform scalar arithmetic.
+    GemmParams p = p_in;
+    if constexpr (Cfg::EPI == EPI_PLAIN && Cfg::OP == OP_I8) {
+        if (p.kchunk > 0) {
+            const int64_t k0 = (int64_t)blockIdx.y * p.kchunk;
+            const int64_t kn = p_in.K - k0 < p.kchunk ? p_in.K - k0 : p.kchunk;
+            p.K = kn > 0 ? kn : 0;
+            p.A += Cfg::A_KMAJOR ? k0 : k0 * p.lda;
+            p.B += Cfg::B_KMAJOR ? k0 : k0 * p.ldb;
+            p.C = (char *)p.C + (int64_t)blockIdx.y * p.M * p.N * 4;
+        }
+    }
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -381,7 +395,8 @@ template <class Cfg> int launch_pp2(const GemmParams &p0, hipStream_t st) {
             return gnk_fail(GNK_ERR_LAUNCH, "gemm: cannot reserve %d bytes of LDS", LDS_TOTAL);
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((gemm_pp2_kernel<Cfg>), dim3((unsigned)(p.grid_m * p.grid_n)), dim3(512), LDS_TOTAL, st, p);
+    const unsigned splits = p.kchunk > 0 ? (unsigned)((p.K + p.kchunk - 1) / p.kchunk) : 1u;
+    hipLaunchKernelGGL((gemm_pp2_kernel<Cfg>), dim3((unsigned)(p.grid_m * p.grid_n), splits), dim3(512), LDS_TOTAL, st, p);
     return gnk_check_launch("gemm (4-stage ping-pong)");
 }
 

@@ -573,3 +573,35 @@ def test_scaled_mm_t_is_the_materialised_transpose(shape, dt):
     want = gn_kernels.scaled_mm(a8, b8, sa, sb).T.contiguous()
     got = gn_kernels.scaled_mm_t(a8, b8, sa, sb)
     torch.testing.assert_close(got.float(), want.float(), rtol=1.6e-2, atol=1e-5 + 5e-5 * float((a8.float().abs() @ b8.float().abs()).max() * sa.float().max() * sb.float().max()))
+
+
+@pytest.mark.parametrize("layout", ["A@B.T", "A.T@B"])
+def test_split_k_on_the_256_kernel_is_bit_identical(layout):
+    """2048 x 2048 x 32768 (the grad-weight GEMM of a square Llama-1B Linear: 64 tiles of 256 x 256 on 256 CUs): the planner cuts K into four
+    chunks on the four-stage 256 x 256 kernel (int32 slabs + reduction kernel).  Integer partial sums add exactly: the result equals the
+    unsplit 128 x 128 kernel's bit for bit, in the forward layout and in the grad-weight layout (both operands M/N-major)."""
+    import gn_kernels
+    from gn_kernels import _cabi
+
+    L = _cabi.load()
+    M = N = 2048
+    K = 32768
+    assert L.gnk_scaled_mm_workspace_bytes(_cabi.I8, _cabi.I8, M, N, K) == 4 * M * N * 4
+    torch.manual_seed(1)
+    if layout == "A@B.T":
+        A = torch.randint(-128, 128, (M, K), dtype=torch.int8, device=DEV)
+        B = torch.randint(-128, 128, (N, K), dtype=torch.int8, device=DEV).T
+    else:
+        A = torch.randint(-128, 128, (K, M), dtype=torch.int8, device=DEV).T
+        B = torch.randint(-128, 128, (K, N), dtype=torch.int8, device=DEV)
+    sa = (torch.rand(M, 1, device=DEV) * 1e-3 + 1e-4).bfloat16()
+    sb = (torch.rand(1, N, device=DEV) * 1e-3 + 1e-4).bfloat16()
+    got = gn_kernels.scaled_mm(A, B, sa, sb)
+    got_t = gn_kernels.scaled_mm_t(A, B, sa, sb)
+    old = L.gnk_set_gemm_variant(1)
+    try:
+        want = gn_kernels.scaled_mm(A, B, sa, sb)
+    finally:
+        L.gnk_set_gemm_variant(old)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    assert torch.equal(got_t.view(torch.int16), want.T.contiguous().view(torch.int16))
