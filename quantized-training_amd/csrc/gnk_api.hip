@@ -254,7 +254,10 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
         // A K-major (A@B.T, A@B): the 8-phase kernel.  Measured at 4096^3 against the 4-stage one (tools/cmp_variants.py, round 2): int8
         // A@B.T 54.0 vs 59.4 us, A@B 56.2 vs 57.5; fp8 (one 16x16x128 MFMA per tile and step instead of two 32x32x64) A@B.T 52.2 vs 59.4,
         // A@B 54.1 vs 55.7.  A M-major (A.T@B) stays on the 4-stage kernel (fp8 55.3 vs 57.9, int8 level).
-        if (variant == GNK_VARIANT_256 && splits == 1 && la.kmajor && ok_128 && whole_steps) variant = GNK_VARIANT_256_PP8;
+        // Exception (tools/pp_choice_probe.py): A@B with a narrow output and a long K (grad-input of the Llama gate / up projections,
+        // 32768 x 2048 x 5632: 315 vs 337 us; x 8192: 446 vs 468) stays on the 4-stage kernel; at K = 2048 the 8-phase kernel wins there too.
+        const bool narrow_long_nn = !lb.kmajor && c.N <= 2048 && c.K >= 4096 && c.M >= 4 * c.N;
+        if (variant == GNK_VARIANT_256 && splits == 1 && la.kmajor && ok_128 && whole_steps && !narrow_long_nn) variant = GNK_VARIANT_256_PP8;
     } else if (variant != GNK_VARIANT_GENERIC &&
                !(variant == GNK_VARIANT_256 ? ok_pp2 : variant == GNK_VARIANT_128 ? ok_128 : (ok_128 && whole_steps))) {
         return gnk_fail(GNK_ERR_UNSUPPORTED, "%s: forced fast variant %d cannot take these strides / sizes", name, variant);
