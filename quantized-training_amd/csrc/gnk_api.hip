@@ -136,35 +136,48 @@ struct GemmCall {
 // M = in, N = out, K = tokens -- leave most CUs idle (1024 x 1024 x 8192: 64 tiles, 63 us); their K range is cut into
 // `splits` chunks, each workgroup writes an int32 partial tile into its own slab of the workspace, and a second kernel
 // adds the slabs (exactly: integers) and applies the scale epilogue (~6 us + 8 B per element and split at ~4 TB/s).
-struct GemmPlan { int variant; int splits; };
+struct GemmPlan { int variant; int splits; int first_steps; };   // first_steps > 0: uneven two-way split, K-steps of split 0
 
 GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, bool can256, bool can128, bool can_split) {
     const double cus = (double)gnk_num_cus();
     const double ksteps = (double)K / 128.0;
-    GemmPlan best = {GNK_VARIANT_GENERIC, 1};
+    GemmPlan best = {GNK_VARIANT_GENERIC, 1, 0};
     double best_t = 1e30;
     if (can256) {
         const double tiles = (double)(((M + 255) / 256) * ((N + 255) / 256));
         const double t = ceil(tiles / cus) * (15.0 + 1.4 * ksteps);
-        if (t < best_t) { best_t = t; best = {GNK_VARIANT_256, 1}; }
+        if (t < best_t) { best_t = t; best = {GNK_VARIANT_256, 1, 0}; }
         // round 2: split-K on the four-stage 256 x 256 kernel too (grad-weights of square Linears, 2048 x 2048 x 32768: 64 tiles)
         if (can_split && K >= 8192) {
             for (int sp = 2; sp <= 8; sp *= 2) {
                 if (K / sp < 2048) break;
                 const double ts = ceil(tiles * sp / cus) * (15.0 + 1.4 * ksteps / sp) + 6.0 + (double)sp * (double)M * (double)N * 8.0 / 4.0e6;
-                if (ts < best_t) { best_t = ts; best = {GNK_VARIANT_256, sp}; }
+                if (ts < best_t) { best_t = ts; best = {GNK_VARIANT_256, sp, 0}; }
+            }
+            // Uneven two-way split for tile counts between half the chip and the whole chip (grad-weights of the Llama-1B MLP,
+            // 2048 x 5632 x 32768: 176 tiles on 256 CUs, where one tile's K loop is the floor of any unsplit launch).  Split 0 of every
+            // tile is dispatched first and holds its CU to the end; the `idle` other CUs take the short second splits in
+            // r = ceil(tiles / idle) rounds; s, the length of a short split, makes both sides end together:
+            //     r * (15 + 1.4 s) = 15 + 1.4 (ksteps - s).
+            if (tiles < cus && tiles > cus / 2) {
+                const double idle = cus - tiles, r = ceil(tiles / idle);
+                const double sshort = floor((15.0 + 1.4 * ksteps - 15.0 * r) / (1.4 * (r + 1.0)));
+                if (sshort >= 16.0 && ksteps - sshort >= 16.0) {
+                    const double ts = 15.0 + 1.4 * (ksteps - sshort) + 6.0 + 2.0 * (double)M * (double)N * 8.0 / 4.0e6;
+                    if (ts < best_t) { best_t = ts; best = {GNK_VARIANT_256, 2, (int)(ksteps - sshort)}; }
+                }
             }
         }
     }
     if (can128) {
         const double tiles = (double)(((M + 127) / 128) * ((N + 127) / 128));
         const double t = ceil(tiles / (2.0 * cus)) * (6.0 + 1.0 * ksteps);
-        if (t < best_t) { best_t = t; best = {GNK_VARIANT_128, 1}; }
+        if (t < best_t) { best_t = t; best = {GNK_VARIANT_128, 1, 0}; }
         if (can_split && K >= 4096) {
             for (int sp = 2; sp <= 8; sp *= 2) {
                 if (K / sp < 512) break;
                 const double ts = ceil(tiles * sp / (2.0 * cus)) * (6.0 + 1.0 * ksteps / sp) + 6.0 + (double)sp * (double)M * (double)N * 8.0 / 4.0e6;
-                if (ts < best_t) { best_t = ts; best = {GNK_VARIANT_128, sp}; }
+                if (ts < best_t) { best_t = ts; best = {GNK_VARIANT_128, sp, 0}; }
             }
         }
     }
@@ -245,12 +258,12 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
     const bool whole_steps = c.K >= GNK_BK && c.K % GNK_BK == 0;
     if ((variant == GNK_VARIANT_256_SIMPLE && op != OP_I8) || ((variant == GNK_VARIANT_256_SIMPLE || variant == GNK_VARIANT_256_PP8) && c.epi == EPI_TILE)) variant = GNK_VARIANT_256;
     if (variant == GNK_VARIANT_256 && c.epi == EPI_TILE) variant = GNK_VARIANT_128;
-    int splits = 1;
+    int splits = 1, first_steps = 0;
     if (variant < 0 || variant > GNK_VARIANT_LAST) {
         const bool can_split = c.ws && op == OP_I8 && c.epi == EPI_ROWCOL && ok_128 && whole_steps && c.N % 4 == 0 && ((uintptr_t)c.C & 15) == 0 && ((uintptr_t)c.ws & 15) == 0;
         const GemmPlan plan = plan_gemm(c.M, c.N, c.K, ok_pp2, ok_128, can_split);
         variant = plan.variant;
-        if (plan.splits > 1 && c.ws_bytes >= (int64_t)plan.splits * c.M * c.N * 4) splits = plan.splits;
+        if (plan.splits > 1 && c.ws_bytes >= (int64_t)plan.splits * c.M * c.N * 4) { splits = plan.splits; first_steps = plan.first_steps; }
         // A K-major (A@B.T, A@B): the 8-phase kernel.  Measured at 4096^3 against the 4-stage one (tools/cmp_variants.py, round 2): int8
         // A@B.T 54.0 vs 59.4 us, A@B 56.2 vs 57.5; fp8 (one 16x16x128 MFMA per tile and step instead of two 32x32x64) A@B.T 52.2 vs 59.4,
         // A@B 54.1 vs 55.7.  A M-major (A.T@B) stays on the 4-stage kernel (fp8 55.3 vs 57.9, int8 level).
@@ -281,9 +294,13 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
             p.A = (const char *)c.A; p.B = (const char *)c.B; p.C = c.ws;
             p.M = c.M; p.N = c.N; p.K = c.K; p.lda = la.ld; p.ldb = lb.ld; p.out_dtype = GNK_I32;
             p.kchunk = ((c.K / GNK_BK + splits - 1) / splits) * GNK_BK;
+            if (first_steps > 0) {                    // uneven two-way split (256 x 256 kernel): split 0 = first_steps K-steps, split 1 = the rest
+                p.kchunk0 = (int64_t)first_steps * GNK_BK;
+                p.kchunk = c.K - p.kchunk0;
+            }
             rc = variant == GNK_VARIANT_256 ? gnk_launch_i8_v0(la.kmajor, lb.kmajor, EPI_PLAIN, p, st) : gnk_launch_i8_v1(la.kmajor, lb.kmajor, EPI_PLAIN, p, st);
             if (rc) return rc;
-            const int nsplit = (int)((c.K + p.kchunk - 1) / p.kchunk);
+            const int nsplit = first_steps > 0 ? 2 : (int)((c.K + p.kchunk - 1) / p.kchunk);
             const unsigned blocks = (unsigned)((c.M * c.N / 4 + 255) / 256);
 #define GNK_REDUCE(OUT) hipLaunchKernelGGL((splitk_reduce_kernel<OUT>), dim3(blocks), dim3(256), 0, st, (const int *)c.ws, c.C, c.s0, c.s1, c.M, c.N, nsplit, c.scale_dtype, c.col_scalar, c.order)
             if (c.out_dtype == GNK_BF16) GNK_REDUCE(GNK_BF16);

@@ -42,6 +42,7 @@ struct GemmParams {
     int grid_m, grid_n;
     int kgroup;       // tile-scaled with QK = kgroup * 128 (kgroup >= 1; 1 for the 64 / 32-k block kernels): K-steps per scale block
     int64_t kchunk;   // split-K: k elements per split (gridDim.y splits, each writing its own (M, N) int32 slab at C); 0 = no split
+    int64_t kchunk0;  // 256 x 256 kernel only: k elements of split 0 when it differs from the others (uneven split); 0 = kchunk
     int debug;        // timing-ablation flags (gnk_set_debug_flags): 1 = no LDS-DMA in the main loop, 2 = no MFMA, 4 = no LDS reads
 };
 

@@ -301,8 +301,12 @@ __global__ void __launch_bounds__(512) gemm_pp2_kernel(const GemmParams p_in) {
     GemmParams p = p_in;
     if constexpr (Cfg::EPI == EPI_PLAIN && Cfg::OP == OP_I8) {
         if (p.kchunk > 0) {
-            const int64_t k0 = (int64_t)blockIdx.y * p.kchunk;
-            const int64_t kn = p_in.K - k0 < p.kchunk ? p_in.K - k0 : p.kchunk;
+            // split 0 may be longer than the others (kchunk0): when the tiles do not fill the chip, the first splits of all tiles occupy
+            // their CUs for the whole launch and the remaining CUs work through the short second splits in rounds (gnk_api.hip:plan_gemm)
+            const int64_t c0 = p.kchunk0 > 0 ? p.kchunk0 : p.kchunk;
+            const int64_t k0 = blockIdx.y == 0 ? 0 : c0 + (int64_t)(blockIdx.y - 1) * p.kchunk;
+            const int64_t len = blockIdx.y == 0 ? c0 : p.kchunk;
+            const int64_t kn = p_in.K - k0 < len ? p_in.K - k0 : len;
             p.K = kn > 0 ? kn : 0;
             p.A += Cfg::A_KMAJOR ? k0 : k0 * p.lda;
             p.B += Cfg::B_KMAJOR ? k0 : k0 * p.ldb;
@@ -395,7 +399,8 @@ template <class Cfg> int launch_pp2(const GemmParams &p0, hipStream_t st) {
             return gnk_fail(GNK_ERR_LAUNCH, "gemm: cannot reserve %d bytes of LDS", LDS_TOTAL);
         attr_set[dev] = true;
     }
-    const unsigned splits = p.kchunk > 0 ? (unsigned)((p.K + p.kchunk - 1) / p.kchunk) : 1u;
+    const int64_t c0 = p.kchunk0 > 0 ? p.kchunk0 : p.kchunk;
+    const unsigned splits = p.kchunk > 0 ? 1u + (unsigned)((p.K - c0 + p.kchunk - 1) / p.kchunk) : 1u;
     hipLaunchKernelGGL((gemm_pp2_kernel<Cfg>), dim3((unsigned)(p.grid_m * p.grid_n), splits), dim3(512), LDS_TOTAL, st, p);
     return gnk_check_launch("gemm (4-stage ping-pong)");
 }

@@ -575,8 +575,9 @@ def test_scaled_mm_t_is_the_materialised_transpose(shape, dt):
     torch.testing.assert_close(got.float(), want.float(), rtol=1.6e-2, atol=1e-5 + 5e-5 * float((a8.float().abs() @ b8.float().abs()).max() * sa.float().max() * sb.float().max()))
 
 
+@pytest.mark.parametrize("N,slabs", [(2048, 4), (5632, 2)])
 @pytest.mark.parametrize("layout", ["A@B.T", "A.T@B"])
-def test_split_k_on_the_256_kernel_is_bit_identical(layout):
+def test_split_k_on_the_256_kernel_is_bit_identical(layout, N, slabs):
     """2048 x 2048 x 32768 (the grad-weight GEMM of a square Llama-1B Linear: 64 tiles of 256 x 256 on 256 CUs): the planner cuts K into four
     chunks on the four-stage 256 x 256 kernel (int32 slabs + reduction kernel).  Integer partial sums add exactly: the result equals the
     unsplit 128 x 128 kernel's bit for bit, in the forward layout and in the grad-weight layout (both operands M/N-major)."""
@@ -584,9 +585,11 @@ def test_split_k_on_the_256_kernel_is_bit_identical(layout):
     from gn_kernels import _cabi
 
     L = _cabi.load()
-    M = N = 2048
+    # N = 5632 (the MLP grad-weights: 176 tiles): an UNEVEN two-way split -- the long first splits hold 176 CUs, the short second ones
+    # run in rounds on the other 80
+    M = 2048
     K = 32768
-    assert L.gnk_scaled_mm_workspace_bytes(_cabi.I8, _cabi.I8, M, N, K) == 4 * M * N * 4
+    assert L.gnk_scaled_mm_workspace_bytes(_cabi.I8, _cabi.I8, M, N, K) == slabs * M * N * 4
     torch.manual_seed(1)
     if layout == "A@B.T":
         A = torch.randint(-128, 128, (M, K), dtype=torch.int8, device=DEV)
