@@ -110,7 +110,12 @@ gnk_gemm_launcher pick_launcher(int op, int fa, int fb, int variant) {
         return variant == GNK_VARIANT_256 ? gnk_launch_i8_v0
                : variant == GNK_VARIANT_256_SIMPLE ? gnk_launch_i8_v3
                : variant == GNK_VARIANT_256_PP8 ? gnk_launch_i8_v4
+               : variant == GNK_VARIANT_256_W4 ? gnk_launch_i8_v5
                                                 : gnk_launch_i8_v1;
+    if (variant == GNK_VARIANT_256_W4) {
+        static const gnk_gemm_launcher f8w4[2][2] = {{gnk_launch_f8_00_v5, gnk_launch_f8_01_v5}, {gnk_launch_f8_10_v5, gnk_launch_f8_11_v5}};
+        return f8w4[fa][fb];
+    }
     if (variant == GNK_VARIANT_256_PP8) {
         static const gnk_gemm_launcher f8pp8[2][2] = {{gnk_launch_f8_00_v4, gnk_launch_f8_01_v4}, {gnk_launch_f8_10_v4, gnk_launch_f8_11_v4}};
         return f8pp8[fa][fb];
@@ -256,7 +261,9 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
     // the 128 x 128 kernel masks a K tail itself (any K; plain and row/col epilogues); the tile-scaled epilogue needs whole 128-k steps
     const bool ok_128 = fast_layout && c.K >= 1 && (c.K % GNK_BK == 0 || c.epi != EPI_TILE) && tile_ok;
     const bool whole_steps = c.K >= GNK_BK && c.K % GNK_BK == 0;
-    if ((variant == GNK_VARIANT_256_SIMPLE && op != OP_I8) || ((variant == GNK_VARIANT_256_SIMPLE || variant == GNK_VARIANT_256_PP8) && c.epi == EPI_TILE)) variant = GNK_VARIANT_256;
+    if ((variant == GNK_VARIANT_256_SIMPLE && op != OP_I8) || ((variant == GNK_VARIANT_256_SIMPLE || variant == GNK_VARIANT_256_PP8 || variant == GNK_VARIANT_256_W4) && c.epi == EPI_TILE)) variant = GNK_VARIANT_256;
+    const bool ok_w4 = ok_pp2 && c.K % 256 == 0;   // one-wave-per-SIMD kernel: four 64-k stages per loop iteration
+    if (variant == GNK_VARIANT_256_W4 && !ok_w4) variant = GNK_VARIANT_256;
     if (variant == GNK_VARIANT_256 && c.epi == EPI_TILE) variant = GNK_VARIANT_128;
     int splits = 1, first_steps = 0;
     if (variant < 0 || variant > GNK_VARIANT_LAST) {
@@ -272,7 +279,7 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
         const bool narrow_long_nn = !lb.kmajor && c.N <= 2048 && c.K >= 4096 && c.M >= 4 * c.N;
         if (variant == GNK_VARIANT_256 && splits == 1 && la.kmajor && ok_128 && whole_steps && !narrow_long_nn) variant = GNK_VARIANT_256_PP8;
     } else if (variant != GNK_VARIANT_GENERIC &&
-               !(variant == GNK_VARIANT_256 ? ok_pp2 : variant == GNK_VARIANT_128 ? ok_128 : (ok_128 && whole_steps))) {
+               !((variant == GNK_VARIANT_256 || variant == GNK_VARIANT_256_W4) ? ok_pp2 : variant == GNK_VARIANT_128 ? ok_128 : (ok_128 && whole_steps))) {
         return gnk_fail(GNK_ERR_UNSUPPORTED, "%s: forced fast variant %d cannot take these strides / sizes", name, variant);
     }
 

@@ -3,6 +3,7 @@
 #include "gnk_gemm_kernel.h"
 #include "gnk_gemm_pp.h"
 #include "gnk_gemm_pp2.h"
+#include "gnk_gemm_w4.h"
 
 // GEMM tile variants (gnk_set_gemm_variant):
 //   0: 256 x 256 tile, 8 waves, four 64-k stages, 2-phase ping-pong (gnk_gemm_pp2.h), 1 workgroup / CU -- large problems
@@ -11,7 +12,8 @@
 //   3: 256 x 256 tile, 8 waves, two-buffer loop (the first kernel; int8 only, kept for A/B timing)
 //   4: 256 x 256 tile, 8 waves, two 128-k buffers, 8-phase ping-pong (gnk_gemm_pp.h): int8, and fp8 on the 16x16x128 MFMA;
 //      the heuristic's choice whenever A is K-major (A@B.T, A@B)
-enum { GNK_VARIANT_256 = 0, GNK_VARIANT_128 = 1, GNK_VARIANT_GENERIC = 2, GNK_VARIANT_256_SIMPLE = 3, GNK_VARIANT_256_PP8 = 4, GNK_VARIANT_LAST = 4 };
+//   5: 256 x 256 tile, 4 waves (one per SIMD, 128 x 128 wave tile), four 64-k stages, one barrier per stage (gnk_gemm_w4.h)
+enum { GNK_VARIANT_256 = 0, GNK_VARIANT_128 = 1, GNK_VARIANT_GENERIC = 2, GNK_VARIANT_256_SIMPLE = 3, GNK_VARIANT_256_PP8 = 4, GNK_VARIANT_256_W4 = 5, GNK_VARIANT_LAST = 5 };
 
 // fp8 format codes as the MFMA's cbsz/blgp fields want them
 enum { F8_E4M3 = 0, F8_E5M2 = 1 };
@@ -29,6 +31,11 @@ GNK_DECLARE_LAUNCHER(gnk_launch_f8_00_v4);
 GNK_DECLARE_LAUNCHER(gnk_launch_f8_01_v4);
 GNK_DECLARE_LAUNCHER(gnk_launch_f8_10_v4);
 GNK_DECLARE_LAUNCHER(gnk_launch_f8_11_v4);
+GNK_DECLARE_LAUNCHER(gnk_launch_i8_v5);
+GNK_DECLARE_LAUNCHER(gnk_launch_f8_00_v5);
+GNK_DECLARE_LAUNCHER(gnk_launch_f8_01_v5);
+GNK_DECLARE_LAUNCHER(gnk_launch_f8_10_v5);
+GNK_DECLARE_LAUNCHER(gnk_launch_f8_11_v5);
 GNK_DECLARE_LAUNCHER(gnk_launch_f8_00_v0);
 GNK_DECLARE_LAUNCHER(gnk_launch_f8_01_v0);
 GNK_DECLARE_LAUNCHER(gnk_launch_f8_10_v0);
@@ -75,6 +82,20 @@ GNK_DECLARE_LAUNCHER(gnk_launch_f8_11_v1);
         switch (epi) {                                                                                      \
         case EPI_PLAIN: return gnk_gemm::launch_pp<GemmCfg<256, 256, 2, 4, AK, BK, OP, FA, FB, EPI_PLAIN>>(p, st);   \
         case EPI_ROWCOL: return gnk_gemm::launch_pp<GemmCfg<256, 256, 2, 4, AK, BK, OP, FA, FB, EPI_ROWCOL>>(p, st); \
+        default: return gnk_gemm::launch<GemmCfg<128, 128, 2, 2, AK, BK, OP, FA, FB, EPI_TILE>>(p, st);     \
+        }                                                                                                   \
+    }                                                                                                       \
+    int NAME(bool a_kmajor, bool b_kmajor, int epi, const GemmParams &p, hipStream_t st) {                  \
+        if (a_kmajor) return b_kmajor ? NAME##_l<true, true>(epi, p, st) : NAME##_l<true, false>(epi, p, st); \
+        return b_kmajor ? NAME##_l<false, true>(epi, p, st) : NAME##_l<false, false>(epi, p, st);           \
+    }
+
+// Variant 5: one wave per SIMD (gnk_gemm_w4.h).
+#define GNK_DEFINE_LAUNCHER_W4(NAME, OP, FA, FB)                                                            \
+    template <bool AK, bool BK> static int NAME##_l(int epi, const GemmParams &p, hipStream_t st) {         \
+        switch (epi) {                                                                                      \
+        case EPI_PLAIN: return gnk_gemm::launch_w4<gnk_gemm::PP2Cfg<AK, BK, OP, FA, FB, EPI_PLAIN>>(p, st);   \
+        case EPI_ROWCOL: return gnk_gemm::launch_w4<gnk_gemm::PP2Cfg<AK, BK, OP, FA, FB, EPI_ROWCOL>>(p, st); \
         default: return gnk_gemm::launch<GemmCfg<128, 128, 2, 2, AK, BK, OP, FA, FB, EPI_TILE>>(p, st);     \
         }                                                                                                   \
     }                                                                                                       \

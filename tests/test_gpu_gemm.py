@@ -12,7 +12,7 @@ from tests._util import FLOAT_DTYPES, FP8_DTYPES, LAYOUTS, bits_equal, load, t_f
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-VARIANTS = {"auto": -1, "tile256": 0, "tile128": 1, "generic": 2, "tile256simple": 3, "tile256pp8": 4}
+VARIANTS = {"auto": -1, "tile256": 0, "tile128": 1, "generic": 2, "tile256simple": 3, "tile256pp8": 4, "tile256w4": 5}
 
 
 @pytest.fixture(params=list(VARIANTS))
@@ -83,7 +83,7 @@ def test_scaled_mm_int8_golden_bit_exact(layout, name, variant):
 
 @pytest.mark.parametrize("layout", list(LAYOUTS))
 def test_tile_scaled_int8_deepseek_golden_bit_exact(layout, variant):
-    if variant in ("tile256", "tile256simple", "tile256pp8"):
+    if variant in ("tile256", "tile256simple", "tile256pp8", "tile256w4"):
         pytest.skip("tile-scaled epilogue has no 256x256 variant (uses the 128x128 tile)")
     g = load("g4_tile_scaled_int8.npz")
     acm, bcm = LAYOUTS[layout]
@@ -114,7 +114,7 @@ def test_fp8_goldens_within_reference_tolerance(tag, variant):
     mag, mag_s, mag_t = fp8_mag(A, B), fp8_mag(A, B, rs, cs), fp8_mag(A, B, sA, sB)
     assert_fp8_close(gn_kernels.scaled_mm(A, B, rs, cs), C_scaled, mag_s)                       # bf16 out (benchmark_mm.py:142)
     assert_fp8_close(gn_kernels.scaled_mm(A, B, rs.float(), cs.float()), C_scaled, mag_s)       # fp32 out
-    if variant not in ("tile256", "tile256simple", "tile256pp8"):
+    if variant not in ("tile256", "tile256simple", "tile256pp8", "tile256w4"):
         assert_fp8_close(gn_kernels.scaled_mm(A, B, sA, sB), C_tile, mag_t)
         assert_fp8_close(gn_kernels.scaled_mm(A, B, sA.float(), sB.float()), C_tile, mag_t)
     assert_fp8_close(gn_kernels._triton_mm(A, B, out_dtype=torch.bfloat16), plain, mag)         # benchmark_mm.py:129

@@ -31,7 +31,10 @@ def main(ks=(256, 1024, 4096, 8192), variants=None):
     S = 4096
     rs = torch.randn(S, 1, device="cuda").div(128).bfloat16()
     cs = torch.randn(1, S, device="cuda").div(128).bfloat16()
-    variants = variants or {"pp2": 0, "pp8": 4, "128": 1}
+    variants = variants or {"pp2": 0, "pp8": 4, "w4": 5}
+    import os
+    if os.environ.get("GNK_CMP_VARIANTS"):   # e.g. GNK_CMP_VARIANTS=w4,pp8
+        variants = {k: v for k, v in variants.items() if k in os.environ["GNK_CMP_VARIANTS"].split(",")}
     for K in ks:
         for name, (acm, bcm) in {"nt": (False, True), "nn": (False, False), "tn": (True, False)}.items():
             A = lay(torch.randint(-128, 127, (S, K), dtype=torch.int8, device="cuda"), acm)
