@@ -28,7 +28,7 @@ int gnk_check_launch(const char *what) {
     return GNK_OK;
 }
 
-static int g_cus[64];
+static std::atomic<int> g_cus[64];   // forward and autograd threads both come through here
 
 #ifdef GNK_ABLATE
 int gnk_debug_flags_get(void) { return g_debug_flags; }
@@ -37,15 +37,15 @@ int gnk_debug_flags_get(void) { return g_debug_flags; }
 int gnk_num_cus(void) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (g_cus[dev] == 0) {
-        int n = 0;
+    int n = g_cus[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        g_cus[dev] = n;
+        g_cus[dev].store(n, std::memory_order_relaxed);
     }
-    return g_cus[dev];
+    return n;
 }
 
-extern "C" int gnk_abi_version(void) { return 1; }
+extern "C" int gnk_abi_version(void) { return GNK_ABI_VERSION; }
 extern "C" const char *gnk_last_error(void) { return g_err; }
 
 extern "C" int gnk_init(void) {
@@ -143,21 +143,24 @@ struct GemmCall {
 // adds the slabs (exactly: integers) and applies the scale epilogue (~6 us + 8 B per element and split at ~4 TB/s).
 struct GemmPlan { int variant; int splits; int first_steps; };   // first_steps > 0: uneven two-way split, K-steps of split 0
 
-GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, bool can256, bool can128, bool can_split) {
+// w4: the 256 x 256 launch would go to the one-wave-per-SIMD kernel (round 3: ~12 fixed, ~1.08 per 128 k -- 2048 x 5632 x 32768 unsplit in
+// 288 us); a split must then promise 8 % to be taken (the uneven two-way split of that shape measured 292 us against 286-290 unsplit).
+GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, bool can256, bool can128, bool can_split, bool w4) {
+    const double fix256 = w4 ? 12.0 : 15.0, per256 = w4 ? 1.08 : 1.4, margin = w4 ? 1.08 : 1.0;
     const double cus = (double)gnk_num_cus();
     const double ksteps = (double)K / 128.0;
     GemmPlan best = {GNK_VARIANT_GENERIC, 1, 0};
     double best_t = 1e30;
     if (can256) {
         const double tiles = (double)(((M + 255) / 256) * ((N + 255) / 256));
-        const double t = ceil(tiles / cus) * (15.0 + 1.4 * ksteps);
+        const double t = ceil(tiles / cus) * (fix256 + per256 * ksteps);
         if (t < best_t) { best_t = t; best = {GNK_VARIANT_256, 1, 0}; }
         // round 2: split-K on the four-stage 256 x 256 kernel too (grad-weights of square Linears, 2048 x 2048 x 32768: 64 tiles)
         if (can_split && K >= 8192) {
             for (int sp = 2; sp <= 8; sp *= 2) {
                 if (K / sp < 2048) break;
-                const double ts = ceil(tiles * sp / cus) * (15.0 + 1.4 * ksteps / sp) + 6.0 + (double)sp * (double)M * (double)N * 8.0 / 4.0e6;
-                if (ts < best_t) { best_t = ts; best = {GNK_VARIANT_256, sp, 0}; }
+                const double ts = ceil(tiles * sp / cus) * (fix256 + per256 * ksteps / sp) + 6.0 + (double)sp * (double)M * (double)N * 8.0 / 4.0e6;
+                if (ts * margin < best_t) { best_t = ts * margin; best = {GNK_VARIANT_256, sp, 0}; }
             }
             // Uneven two-way split for tile counts between half the chip and the whole chip (grad-weights of the Llama-1B MLP,
             // 2048 x 5632 x 32768: 176 tiles on 256 CUs, where one tile's K loop is the floor of any unsplit launch).  Split 0 of every
@@ -166,10 +169,10 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, bool can256, bool can128, bo
             //     r * (15 + 1.4 s) = 15 + 1.4 (ksteps - s).
             if (tiles < cus && tiles > cus / 2) {
                 const double idle = cus - tiles, r = ceil(tiles / idle);
-                const double sshort = floor((15.0 + 1.4 * ksteps - 15.0 * r) / (1.4 * (r + 1.0)));
+                const double sshort = floor((fix256 + per256 * ksteps - fix256 * r) / (per256 * (r + 1.0)));
                 if (sshort >= 16.0 && ksteps - sshort >= 16.0) {
-                    const double ts = 15.0 + 1.4 * (ksteps - sshort) + 6.0 + 2.0 * (double)M * (double)N * 8.0 / 4.0e6;
-                    if (ts < best_t) { best_t = ts; best = {GNK_VARIANT_256, 2, (int)(ksteps - sshort)}; }
+                    const double ts = fix256 + per256 * (ksteps - sshort) + 6.0 + 2.0 * (double)M * (double)N * 8.0 / 4.0e6;
+                    if (ts * margin < best_t) { best_t = ts * margin; best = {GNK_VARIANT_256, 2, (int)(ksteps - sshort)}; }
                 }
             }
         }
@@ -268,12 +271,30 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
     int splits = 1, first_steps = 0;
     if (variant < 0 || variant > GNK_VARIANT_LAST) {
         const bool can_split = c.ws && op == OP_I8 && c.epi == EPI_ROWCOL && ok_128 && whole_steps && c.N % 4 == 0 && ((uintptr_t)c.C & 15) == 0 && ((uintptr_t)c.ws & 15) == 0;
-        const GemmPlan plan = plan_gemm(c.M, c.N, c.K, ok_pp2, ok_128, can_split);
+        const GemmPlan plan = plan_gemm(c.M, c.N, c.K, ok_pp2, ok_128, can_split, ok_w4 && variant != GNK_VARIANT_AUTO_NO_W4);
+        const bool allow_w4 = variant != GNK_VARIANT_AUTO_NO_W4;
         variant = plan.variant;
         if (plan.splits > 1 && c.ws_bytes >= (int64_t)plan.splits * c.M * c.N * 4) { splits = plan.splits; first_steps = plan.first_steps; }
-        // A K-major (A@B.T, A@B): the 8-phase kernel.  Measured at 4096^3 against the 4-stage one (tools/cmp_variants.py, round 2): int8
-        // A@B.T 54.0 vs 59.4 us, A@B 56.2 vs 57.5; fp8 (one 16x16x128 MFMA per tile and step instead of two 32x32x64) A@B.T 52.2 vs 59.4,
-        // A@B 54.1 vs 55.7.  A M-major (A.T@B) stays on the 4-stage kernel (fp8 55.3 vs 57.9, int8 level).
+        // Round 3: the one-wave-per-SIMD kernel takes every 256 x 256 launch it can (K a multiple of 256; split-K chunks likewise).  Measured at
+        // 4096^3 against the 8-phase kernel on one box (tools/cmp_variants.py): int8 A@B.T 57.4 vs 57.9 us, A@B 56.6 vs 59.8, A.T@B 56.8 vs 64.0;
+        // fp8 56.0 / 55.6 / 55.7 vs 55.8 / 57.6 / 61.2; at K = 8192 101.0-102.6 vs 103.7-117.5.
+        // Exception: both operands K-major (A@B.T) with more tiles than CUs -- the forward GEMMs of training (32768 x {2048, 5632} x 2048: 113-120 vs
+        // 119-129 us, 298 vs 313; x 2048 x 5632: 268 vs 291) stay on the 8-phase kernel: both K-major super-stages fall free in the same (odd)
+        // stage, where 16 LDS-DMA issues per wave do not hide behind 64 MFMAs.
+        const bool kk_many_tiles = la.kmajor && lb.kmajor && ((c.M + 255) / 256) * ((c.N + 255) / 256) > gnk_num_cus() && ok_128 && whole_steps;
+        if (variant == GNK_VARIANT_256 && allow_w4 && ok_w4 && !(kk_many_tiles && splits == 1)) {
+            if (splits == 1) {
+                variant = GNK_VARIANT_256_W4;
+            } else if (first_steps > 0) {
+                first_steps += first_steps & 1;
+                if ((int64_t)first_steps * GNK_BK < c.K) variant = GNK_VARIANT_256_W4;
+            } else if ((((c.K / GNK_BK + splits - 1) / splits) * GNK_BK) % 256 == 0) {
+                variant = GNK_VARIANT_256_W4;
+            }
+        }
+        // Without it (K % 256 != 0), A K-major (A@B.T, A@B): the 8-phase kernel.  Measured at 4096^3 against the 4-stage one (tools/cmp_variants.py,
+        // round 2): int8 A@B.T 54.0 vs 59.4 us, A@B 56.2 vs 57.5; fp8 (one 16x16x128 MFMA per tile and step instead of two 32x32x64) A@B.T 52.2 vs
+        // 59.4, A@B 54.1 vs 55.7.  A M-major (A.T@B) stays on the 4-stage kernel (fp8 55.3 vs 57.9, int8 level).
         // Exception (tools/pp_choice_probe.py): A@B with a narrow output and a long K (grad-input of the Llama gate / up projections,
         // 32768 x 2048 x 5632: 315 vs 337 us; x 8192: 446 vs 468) stays on the 4-stage kernel; at K = 2048 the 8-phase kernel wins there too.
         const bool narrow_long_nn = !lb.kmajor && c.N <= 2048 && c.K >= 4096 && c.M >= 4 * c.N;
@@ -305,7 +326,8 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
                 p.kchunk0 = (int64_t)first_steps * GNK_BK;
                 p.kchunk = c.K - p.kchunk0;
             }
-            rc = variant == GNK_VARIANT_256 ? gnk_launch_i8_v0(la.kmajor, lb.kmajor, EPI_PLAIN, p, st) : gnk_launch_i8_v1(la.kmajor, lb.kmajor, EPI_PLAIN, p, st);
+            rc = variant == GNK_VARIANT_256_W4 ? gnk_launch_i8_v5(la.kmajor, lb.kmajor, EPI_PLAIN, p, st)
+                 : variant == GNK_VARIANT_256 ? gnk_launch_i8_v0(la.kmajor, lb.kmajor, EPI_PLAIN, p, st) : gnk_launch_i8_v1(la.kmajor, lb.kmajor, EPI_PLAIN, p, st);
             if (rc) return rc;
             const int nsplit = first_steps > 0 ? 2 : (int)((c.K + p.kchunk - 1) / p.kchunk);
             const unsigned blocks = (unsigned)((c.M * c.N / 4 + 255) / 256);
@@ -361,8 +383,10 @@ extern "C" int gnk_scaled_mm(const void *A, int a_dtype, const void *B, int b_dt
 extern "C" int64_t gnk_scaled_mm_workspace_bytes(int a_dtype, int b_dtype, int64_t M, int64_t N, int64_t K) {
     if (a_dtype != GNK_I8 || b_dtype != GNK_I8 || M <= 0 || N <= 0) return 0;
     if (K < GNK_BK || K % GNK_BK != 0 || N % 4 != 0) return 0;
-    const GemmPlan plan = plan_gemm(M, N, K, true, true, true);   // layout / alignment are re-checked at launch
-    return plan.splits > 1 ? (int64_t)plan.splits * M * N * 4 : 0;
+    // layout / alignment are re-checked at launch, where the plan is the one of the kernel that takes the call: offer room for either
+    const GemmPlan plan = plan_gemm(M, N, K, true, true, true, false), plan4 = plan_gemm(M, N, K, true, true, true, K % 256 == 0);
+    const int splits = plan.splits > plan4.splits ? plan.splits : plan4.splits;
+    return splits > 1 ? (int64_t)splits * M * N * 4 : 0;
 }
 
 extern "C" int gnk_scaled_mm_ws(const void *A, int a_dtype, const void *B, int b_dtype, void *C, int out_dtype,

@@ -21,6 +21,7 @@
 //     consecutive n for one m: the epilogue packs them into one 8-byte (bf16) / 16-byte store;
 //   * workgroups are remapped so that the 8 XCDs (private L2s) each own a compact patch of tiles.
 #pragma once
+#include <atomic>
 #include "gnk_common.h"
 #include "gnk_lds_layout.h"
 
@@ -863,13 +864,13 @@ template <class Cfg> int launch(const GemmParams &p0, hipStream_t st) {
     GemmParams p = p0;
     p.grid_m = (int)((p.M + Cfg::BM - 1) / Cfg::BM);
     p.grid_n = (int)((p.N + Cfg::BN - 1) / Cfg::BN);
-    static bool attr_set[64] = {};   // opt in to > 64 KiB of dynamic LDS once per device and kernel instance
+    static std::atomic<bool> attr_set[64];   // opt in to > 64 KiB of dynamic LDS once per device and kernel instance
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return gnk_fail(GNK_ERR_LAUNCH, "gemm: no current HIP device");
-    if (!attr_set[dev]) {
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute((const void *)gemm_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess)
             return gnk_fail(GNK_ERR_LAUNCH, "gemm: cannot reserve %d bytes of LDS", LDS_TOTAL);
-        attr_set[dev] = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     const unsigned splits = p.kchunk > 0 ? (unsigned)((p.K + p.kchunk - 1) / p.kchunk) : 1u;
     hipLaunchKernelGGL((gemm_kernel<Cfg>), dim3((unsigned)(p.grid_m * p.grid_n), splits), dim3(Cfg::NT), LDS_TOTAL, st, p);

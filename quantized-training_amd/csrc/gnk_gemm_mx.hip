@@ -1,3 +1,4 @@
+#include <atomic>
 // gnk_gemm_mx.hip -- MXFP4 and MXFP8 GEMMs on CDNA4's block-scaled MFMA.
 //
 //   C(M x N, bf16) = cast( sum over 32-k blocks kb of  (A_kb . B_kb) * 2^(sA[m,kb]-127) * 2^(sB[n,kb]-127)  (+ bias[n]) )
@@ -557,14 +558,14 @@ __global__ void __launch_bounds__(256) mxfp8_generic_kernel(const MxParams mp, i
 inline bool al(const void *p, int a) { return ((uintptr_t)p % a) == 0; }
 
 template <int FA, int FB> int launch_mxfp8(const MxParams &mp, bool big, hipStream_t st) {
-    static bool attr_set[64][2] = {};
+    static std::atomic<bool> attr_set[64][2];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return gnk_fail(GNK_ERR_LAUNCH, "mxfp8_mm: no current HIP device");
-    if (!attr_set[dev][big]) {
+    if (!attr_set[dev][big].load(std::memory_order_acquire)) {
         const hipError_t e = big ? hipFuncSetAttribute((const void *)mxfp8_256_kernel<FA, FB>, hipFuncAttributeMaxDynamicSharedMemorySize, MX8_256_LDS)
                                  : hipFuncSetAttribute((const void *)mx_kernel<4, FA, FB>, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS);
         if (e != hipSuccess) return gnk_fail(GNK_ERR_LAUNCH, "mxfp8_mm: cannot reserve %d bytes of LDS", big ? MX8_256_LDS : MX_LDS);
-        attr_set[dev][big] = true;
+        attr_set[dev][big].store(true, std::memory_order_release);
     }
     if (big) hipLaunchKernelGGL((mxfp8_256_kernel<FA, FB>), dim3((unsigned)(mp.g.grid_m * mp.g.grid_n)), dim3(512), MX8_256_LDS, st, mp);
     else hipLaunchKernelGGL((mx_kernel<4, FA, FB>), dim3((unsigned)(mp.g.grid_m * mp.g.grid_n)), dim3(256), MX_LDS, st, mp);
@@ -618,13 +619,13 @@ extern "C" int gnk_mxfp4_mm(const void *A, const void *B, void *C, int out_dtype
     if (fast) {
         mp.g.grid_m = (int)((M + 127) / 128);
         mp.g.grid_n = (int)((N + 127) / 128);
-        static bool attr_set[64] = {};
+        static std::atomic<bool> attr_set[64];
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return gnk_fail(GNK_ERR_LAUNCH, "mxfp4_mm: no current HIP device");
-        if (!attr_set[dev]) {
+        if (!attr_set[dev].load(std::memory_order_acquire)) {
             if (hipFuncSetAttribute((const void *)mx_kernel<8, FMT_FP4, FMT_FP4>, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS) != hipSuccess)
                 return gnk_fail(GNK_ERR_LAUNCH, "mxfp4_mm: cannot reserve %d bytes of LDS", MX_LDS);
-            attr_set[dev] = true;
+            attr_set[dev].store(true, std::memory_order_release);
         }
         hipLaunchKernelGGL((mx_kernel<8, FMT_FP4, FMT_FP4>), dim3((unsigned)(mp.g.grid_m * mp.g.grid_n)), dim3(256), MX_LDS, st, mp);
         return gnk_check_launch("mxfp4_mm");

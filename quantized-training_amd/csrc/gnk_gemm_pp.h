@@ -25,6 +25,7 @@
 // one barrier later.  Tile t+1 is complete when every wave has passed its own vmcnt(0) in p5 and
 // the barrier that follows; its first reader is p7.
 #pragma once
+#include <atomic>
 #include "gnk_gemm_kernel.h"
 
 namespace gnk_gemm {
@@ -203,13 +204,13 @@ template <class Cfg> int launch_pp(const GemmParams &p0, hipStream_t st) {
     GemmParams p = p0;
     p.grid_m = (int)((p.M + 255) / 256);
     p.grid_n = (int)((p.N + 255) / 256);
-    static bool attr_set[64] = {};
+    static std::atomic<bool> attr_set[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return gnk_fail(GNK_ERR_LAUNCH, "gemm: no current HIP device");
-    if (!attr_set[dev]) {
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute((const void *)gemm_pp_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess)
             return gnk_fail(GNK_ERR_LAUNCH, "gemm: cannot reserve %d bytes of LDS", LDS_TOTAL);
-        attr_set[dev] = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((gemm_pp_kernel<Cfg>), dim3((unsigned)(p.grid_m * p.grid_n)), dim3(512), LDS_TOTAL, st, p);
     return gnk_check_launch("gemm (ping-pong)");

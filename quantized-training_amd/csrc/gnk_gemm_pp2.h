@@ -22,6 +22,7 @@
 // overwrites its buffer is issued in LOAD(s), at least one barrier after both.  Stage s+2 is first read
 // in LOAD(s+1), after every wave's own vmcnt in LOAD(s) and the barrier(s) that follow.
 #pragma once
+#include <atomic>
 #include "gnk_gemm_kernel.h"
 
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -391,13 +392,13 @@ template <class Cfg> int launch_pp2(const GemmParams &p0, hipStream_t st) {
     GemmParams p = p0;
     p.grid_m = (int)((p.M + 255) / 256);
     p.grid_n = (int)((p.N + 255) / 256);
-    static bool attr_set[64] = {};
+    static std::atomic<bool> attr_set[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return gnk_fail(GNK_ERR_LAUNCH, "gemm: no current HIP device");
-    if (!attr_set[dev]) {
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute((const void *)gemm_pp2_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess)
             return gnk_fail(GNK_ERR_LAUNCH, "gemm: cannot reserve %d bytes of LDS", LDS_TOTAL);
-        attr_set[dev] = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     const int64_t c0 = p.kchunk0 > 0 ? p.kchunk0 : p.kchunk;
     const unsigned splits = p.kchunk > 0 ? 1u + (unsigned)((p.K - c0 + p.kchunk - 1) / p.kchunk) : 1u;

@@ -4,18 +4,20 @@
 // SIMD and hand the matrix pipe from one to the other at a barrier 4-8 times per 128 k; their PMC shows the pipe busy 55-58 % of
 // the dispatch.  Here a workgroup is 4 waves (2 x 2), each alone on its SIMD with a 128 x 128 wave tile:
 //   * 256 accumulator registers per lane (the whole AGPR half of the 512-entry file), two complete fragment sets in VGPRs;
-//   * LDS holds a ring of four 64-k stages (A 256 x 64 B + B 256 x 64 B = 32 KiB each); three stages of LDS-DMA are in flight;
+//   * LDS holds four 64-k stages of each operand (64 KiB + 64 KiB): an M/N-major operand as a ring of four [64 k][256 B] stages, a
+//     K-major one as a ring of two 128-k super-stages [256 rows][128 B], so that every LDS-DMA piece fetches whole 128-byte lines
+//     (with 64-byte row segments A@B.T ran 9 % behind A.T@B: twice the L2 requests); two to three stages of LDS-DMA are in flight;
 //   * per stage a wave issues 64 x v_mfma_i32_16x16x64_i8 (or 16 x v_mfma_f32_32x32x64_f8f6f4) from fragment set `cur`
 //     while the SAME wave, between those MFMAs, reads the next stage's fragments into set `nxt` (16 x ds_read_b128 per 64 MFMAs
 //     instead of 12 per 32: a third less LDS traffic per MFMA than the 128 x 64 wave tile) and issues its 8 LDS-DMA pieces of
 //     stage t + 4;
 //   * ONE barrier per stage.  No MFMA ever waits for an LDS read issued in the same stage.
 // Stage t, every wave:
-//     vmcnt(16): my pieces of stage t+1 have landed | lgkmcnt(0): set `cur` (stage t) is in registers | s_barrier
+//     vmcnt(n): my pieces of stage t+1 have landed (n from the issue order, tools/gen_w4_asm.py) | lgkmcnt(0): set `cur` (stage t) is in registers | s_barrier
 //     MFMAs of stage t, and behind them: the reads of stage t+1 -> nxt (first half of the stage), the DMA pieces of stage t+4 -> buffer t & 3
 // Buffer safety: buffer t & 3 (stage t) was read during stage t-1; every wave retired those reads (lgkmcnt(0)) before
 // the barrier above, and the DMA that overwrites it is issued after that barrier.  Stage t+1 is read after the barrier that
-// follows every wave's own vmcnt(16).  The loop is branch-free: past the end of K the base pointers stop advancing, so the surplus
+// follows every wave's own vmcnt(n).  The loop is branch-free: past the end of K the base pointers stop advancing, so the surplus
 // pieces re-fetch the last stage into a buffer nobody reads again (valid memory, L2 hits) and the vmcnt count never changes.
 // The main loop is hand-scheduled inline asm (gnk_gemm_w4_asm.inc, written by tools/gen_w4_asm.py, which also states the fixed
 // register plan): under hipcc the same program rotated its accumulators through ~100 v_accvgpr copies per four stages and ran
@@ -33,31 +35,32 @@ static __device__ unsigned long long gnk_w4_stamps[4096];   // one copy per inst
 
 namespace gnk_gemm {
 
-// This wave's four 1-KiB pieces of one operand stage (256 rows x 64 k), four waves per workgroup.
+// This wave's 1-KiB pieces of one operand, four waves per workgroup: four per 64-k stage of an M/N-major operand (256 B x 64 k), eight
+// per 128-k super-stage of a K-major one (256 rows x 128 B: whole 128-byte lines per row, the image of the 8-phase kernel).
 template <bool KMAJOR> struct StagerW4 {
     const char *base;
-    unsigned off[4];
+    unsigned off[8];
     int64_t step;
     __device__ __forceinline__ void init(const char *ptr, int64_t ld, int64_t r0, int64_t extent, int wave, int lane) {
         base = KMAJOR ? ptr + r0 * ld : ptr + r0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 8; ++i) {
             const int p = (i * 4 + wave) * 64 + lane;
             if constexpr (KMAJOR) {
                 int r, c;
-                gnk_k64_stage_src(p, r, c);
+                gnk_kmaj_stage_src(p, r, c);
                 const int64_t rmax = extent - 1 - r0;
                 const int64_t row = r < rmax ? r : rmax;
                 off[i] = (unsigned)(row * ld + 16 * c);
             } else {
                 int k, c;
-                gnk_mn64_stage_src(p, k, c);
+                gnk_mn64_stage_src(p & 1023, k, c);
                 const int64_t cmax = extent - 16 - r0;
                 const int64_t col = 16 * c < cmax ? 16 * c : cmax;
-                off[i] = (unsigned)((int64_t)k * ld + col);
+                off[i] = (unsigned)((int64_t)k * ld + col);   // pieces 4-7 repeat 0-3 (unused)
             }
         }
-        step = KMAJOR ? 64 : 64 * ld;
+        step = KMAJOR ? 128 : 64 * ld;
     }
 };
 
@@ -76,7 +79,7 @@ template <int N> __device__ __forceinline__ void w4_read16(int (&r)[16]) {
 template <class Cfg> struct W4I8 {
     typedef PP2I8<Cfg> Base;
     static __device__ __forceinline__ unsigned frag0(bool kmajor, int rb, int lane) {
-        return kmajor ? (unsigned)gnk_k64_frag16_offset(rb, lane) : (unsigned)gnk_mn64_frag16_offset(rb, 0, lane);
+        return kmajor ? (unsigned)gnk_kmaj_frag_offset(rb, 0, lane) : (unsigned)gnk_mn64_frag16_offset(rb, 0, lane);
     }
     template <int H, int I> static __device__ __forceinline__ void fetch_row(typename Base::acc_arr &acc) {
         int r[16];
@@ -97,7 +100,7 @@ template <class Cfg> struct W4I8 {
 template <class Cfg> struct W4F8 {
     typedef PP2F8<Cfg> Base;
     static __device__ __forceinline__ unsigned frag0(bool kmajor, int rb, int lane) {
-        return kmajor ? (unsigned)gnk_k64_frag_offset(rb, 0, lane) : (unsigned)gnk_mn64_frag_offset(rb, 0, 0, lane);
+        return kmajor ? (unsigned)gnk_kmaj_offset(rb + (lane & 31), lane >> 5) : (unsigned)gnk_mn64_frag_offset(rb, 0, 0, lane);
     }
     template <int H, int T> static __device__ __forceinline__ void fetch_tile(typename Base::acc_arr &acc) {
         int r[16];
@@ -175,9 +178,12 @@ __global__ void __launch_bounds__(256) gemm_w4_kernel(const GemmParams p_in) {
 
 #define GNK_W4_RUN(TEXT)                                                                                                              \
     asm volatile(TEXT : : [alo] "s"(alo), [ahi] "s"(ahi), [blo] "s"(blo), [bhi] "s"(bhi), [stepa] "s"(stepa), [stepb] "s"(stepb),      \
-                 [lds] "s"(ldsw), [nit] "s"(nit), [rem] "s"(rem), [va] "v"(va), [vb] "v"(vb), [o0] "v"(sa.off[0]), [o1] "v"(sa.off[1]), \
-                 [o2] "v"(sa.off[2]), [o3] "v"(sa.off[3]), [o4] "v"(sb.off[0]), [o5] "v"(sb.off[1]), [o6] "v"(sb.off[2]),              \
-                 [o7] "v"(sb.off[3]), [fa] "i"(Cfg::FA), [fb] "i"(Cfg::FB) : GNK_W4_CLOBBERS)
+                 [lds] "s"(ldsw), [nit] "s"(nit), [rem] "s"(rem), [va] "v"(va), [vb] "v"(vb),                                         \
+                 [oa0] "v"(sa.off[0]), [oa1] "v"(sa.off[1]), [oa2] "v"(sa.off[2]), [oa3] "v"(sa.off[3]),                              \
+                 [oa4] "v"(sa.off[4]), [oa5] "v"(sa.off[5]), [oa6] "v"(sa.off[6]), [oa7] "v"(sa.off[7]),                              \
+                 [ob0] "v"(sb.off[0]), [ob1] "v"(sb.off[1]), [ob2] "v"(sb.off[2]), [ob3] "v"(sb.off[3]),                              \
+                 [ob4] "v"(sb.off[4]), [ob5] "v"(sb.off[5]), [ob6] "v"(sb.off[6]), [ob7] "v"(sb.off[7]),                              \
+                 [fa] "i"(Cfg::FA), [fb] "i"(Cfg::FB) : GNK_W4_CLOBBERS)
     if constexpr (Cfg::OP == OP_I8) {
         if constexpr (Cfg::A_KMAJOR && Cfg::B_KMAJOR) GNK_W4_RUN(GNK_W4_ASM_I8_KK);
         else if constexpr (Cfg::A_KMAJOR) GNK_W4_RUN(GNK_W4_ASM_I8_KM);

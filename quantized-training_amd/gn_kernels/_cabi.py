@@ -11,7 +11,7 @@ import torch
 
 # GNK_LIBRARY: tuning only (an A/B build of the same sources, e.g. `make ABLATE=1 OUT=...`); the shipped library is the default
 _LIB_PATH = Path(os.environ.get("GNK_LIBRARY") or Path(__file__).resolve().parent / "libgnk_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2   # include/gnk.h GNK_ABI_VERSION
 
 BF16, F16, F32, I8, E4M3, E5M2, I32 = range(7)
 DTYPE_CODE = {

@@ -419,7 +419,9 @@ def test_full_size_4096_fp8_scaled_all_layouts(layout):
     mag = (A.float().abs() * rs.float().abs()) @ (B.float().abs() * cs.float().abs())
     bound = 1.6e-2 * want.abs() + 5e-5 * mag + 1e-5
     assert not bool(((out.float() - want).abs() > bound).any())
-    _record(f"scaled_fp8_4096_{layout}", {"failing": _unwidened_failures(out, want), "of": S * S})
+    failing = _unwidened_failures(out, want)
+    _record(f"scaled_fp8_4096_{layout}", {"failing": failing, "of": S * S})
+    assert failing == 0, "scaled fp8 must pass the reference's own unwidened assert_close (benchmark_mm.py:142-143)"
     plain = gn_kernels._triton_mm(A, B, out_dtype=torch.bfloat16)
     wantp = A.float() @ B.float()
     magp = A.float().abs() @ B.float().abs()
@@ -454,7 +456,9 @@ def test_full_size_4096_fp8_tile_scaled(style, layout):
     mag = a_abs @ b_abs
     bound = 1.6e-2 * want.abs() + 5e-5 * mag + 1e-5
     assert not bool(((out.float() - want).abs() > bound).any())
-    _record(f"tile_fp8_4096_{style}_{layout}", {"failing": _unwidened_failures(out, want), "of": S * S})
+    failing = _unwidened_failures(out, want)
+    _record(f"tile_fp8_4096_{style}_{layout}", {"failing": failing, "of": S * S})
+    assert failing == 0, "tile-scaled fp8 must pass the reference's own unwidened assert_close (benchmark_mm.py:144-145)"
     # oracle on one block of rows over 256 columns (fp8 decode + fp32 partial sums + the three-rounding rescale on the host)
     r0 = 97 * 32
     rows = slice(r0, r0 + 32)
@@ -492,7 +496,9 @@ def test_auto_dispatch_at_benchmark_mid_sizes(S, layout):
     want8 = _scaled_ref(A8, B8, rs, cs)
     mag8 = (A8.float().abs() * rs.float().abs()) @ (B8.float().abs() * cs.float().abs())
     assert not bool(((out8.float() - want8).abs() > 1.6e-2 * want8.abs() + 5e-5 * mag8 + 1e-5).any())
-    _record(f"scaled_fp8_{S}_{layout}", {"failing": _unwidened_failures(out8, want8), "of": S * S})
+    failing = _unwidened_failures(out8, want8)
+    _record(f"scaled_fp8_{S}_{layout}", {"failing": failing, "of": S * S})
+    assert failing == 0, "scaled fp8 must pass the reference's own unwidened assert_close (benchmark_mm.py:142-143)"
 
 
 def test_tile_scaled_refuses_ragged_scale_tilings():

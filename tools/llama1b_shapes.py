@@ -45,13 +45,13 @@ for name, (K, N), count in (("q/k/v/o", (2048, 2048), 4), ("gate/up", (2048, 563
     }
     for cname, fn in cases.items():
         row = []
-        for vn, v in (("pp8", 4), ("auto", -1), ("pp2", 0), ("128", 1), ("auto", -1)):
+        for vn, v in (("pp8", 4), ("w4", 5), ("auto", -1), ("auto-no-w4", -2), ("pp2", 0), ("auto", -1), ("auto-no-w4", -2)):
             L.gnk_set_gemm_variant(v)
             try:
                 t = timeit(fn)
-                row.append(f"{vn} {t:7.1f} us {2 * T * K * N / t / 1e6:5.0f} T")
-                if vn == "auto":
-                    tot[cname] = tot.get(cname, 0.0) + count * t
+                row.append(f"{vn} {t:6.1f} {2 * T * K * N / t / 1e6:4.0f}T")
+                if vn.startswith("auto"):
+                    tot[vn + " " + cname] = tot.get(vn + " " + cname, 0.0) + count * t / 2
             except Exception as exc:
                 row.append(f"{vn} failed")
         L.gnk_set_gemm_variant(-1)
