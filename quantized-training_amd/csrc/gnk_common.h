@@ -246,3 +246,22 @@ template <int DT> struct GnkAbsMax {
         else return __float_as_uint(gnk_f16_to_f32((unsigned short)h));
     }
 };
+
+// 16-byte store of a finished output tile row segment.  GNK_STORE_MODE (experiment, tools/store_mode_ab.sh): 0 plain write-back store;
+// 1 non-temporal; 2 sc1 (agent scope: written through the XCD's L2); 3 sc0 sc1 (system scope); 4 sc1 nt.
+#ifndef GNK_STORE_MODE
+#define GNK_STORE_MODE 0
+#endif
+__device__ __forceinline__ void gnk_store16_out(void *ptr, const v4i &d) {
+#if GNK_STORE_MODE == 0
+    *(v4i *)ptr = d;
+#elif GNK_STORE_MODE == 1
+    __builtin_nontemporal_store(d, (v4i *)ptr);
+#elif GNK_STORE_MODE == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(ptr), "v"(d) : "memory");
+#elif GNK_STORE_MODE == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(ptr), "v"(d) : "memory");
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(ptr), "v"(d) : "memory");
+#endif
+}

@@ -255,7 +255,7 @@ template <class Cfg> struct PP2F8 {
                 for (int it = 4 * i; it < 4 * i + 4; ++it) {
                     const int row = it * 8 + srow;
                     const v4i d = *(const GNK_LDS v4i *)(const GNK_LDS char *)(region + row * 128 + ((sc8 ^ (row & 7)) << 4));
-                    if (col_ok && it * 8 < rows_left) *(v4i *)(cbase + it * cstep) = d;
+                    if (col_ok && it * 8 < rows_left) gnk_store16_out(cbase + it * cstep, d);
                 }
             }
         }
