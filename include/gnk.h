@@ -43,7 +43,7 @@ typedef enum gnk_status {
  * the meaning of an argument or return code (kernel changes behind an unchanged signature do not count); a binding compares
  * gnk_abi_version() of the loaded library with the GNK_ABI_VERSION it was written against and refuses a mismatch.
  *   1: round 1.   2: rounds 2-3 -- gnk_scaled_mm_ws / gnk_scaled_mm_t, the fused quantize pair, gnk_quantize_int8_noalloc, the MX and BitNet
- *      entry points added; gnk_set_debug_flags removed from the shipped library; gnk_set_gemm_variant accepts 5 and -2. */
+ *      entry points added; gnk_set_debug_flags removed from the shipped library; gnk_set_gemm_variant accepts 5 and -2; gnk_set_tile_rescale added. */
 #define GNK_ABI_VERSION 2
 int gnk_abi_version(void);
 
@@ -229,6 +229,17 @@ int gnk_bitnet_unpack_i2(const void *x, int64_t nbytes, void *out, void *stream)
  * value.  Variants are listed in csrc/gnk_gemm_dispatch.h.
  */
 int gnk_set_gemm_variant(int variant);
+
+/*
+ * Rescale form of gnk_tile_scaled_mm's fast kernels for subsequent calls on this thread (returns the previous mode):
+ *   0 (default): fp32 outputs use the reference interpreter's form acc += (f32(part) * sA) * sB, three separately rounded operations
+ *      (triton_mm.py:327-331 run under TRITON_INTERPRET=1; goldens g4 are bit-exact), bf16 / fp16 outputs use
+ *      acc = fma(f32(part), sA * sB, acc): within the reference's tolerance for this op (benchmark_mm.py:119-121: atol 1e-4, rtol 1e-2;
+ *      fp8 :144-145: bf16 assert_close defaults), half the vector instructions, about 1.4x the throughput;
+ *   1: the three-rounding form for every output dtype;   2: the fused form for every output dtype.
+ * The generic fallback kernel (odd block sizes) always uses the three-rounding form.  No reference counterpart.
+ */
+int gnk_set_tile_rescale(int mode);
 
 /*
  * gnk_quantize_int8 for callers that CANNOT allocate device memory (code under HIP graph capture, tight serving loops,

@@ -10,6 +10,7 @@
 // ------------------------------------------------------------------ error plumbing
 static thread_local char g_err[512] = "";
 static thread_local int g_forced_variant = -1;
+static thread_local int g_tile_rescale = 0;   // gnk_set_tile_rescale: 0 auto, 1 exact, 2 fused
 #ifdef GNK_ABLATE
 static thread_local int g_debug_flags = 0;
 #endif
@@ -67,6 +68,12 @@ int gnk_forced_variant_get(void) { return g_forced_variant; }
 extern "C" int gnk_set_gemm_variant(int variant) {
     const int old = g_forced_variant;
     g_forced_variant = variant;
+    return old;
+}
+
+extern "C" int gnk_set_tile_rescale(int mode) {
+    const int old = g_tile_rescale;
+    g_tile_rescale = mode < 0 || mode > 2 ? 0 : mode;
     return old;
 }
 
@@ -347,6 +354,9 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
     p.ssam = c.ssam; p.ssak = c.ssak; p.ssbk = c.ssbk; p.ssbn = c.ssbn; p.QM = c.QM; p.QN = c.QN;
     p.out_dtype = c.out_dtype; p.scale_dtype = c.scale_dtype; p.col_scalar = c.col_scalar; p.order = c.order;
     p.debug = gnk_debug_flags_get();
+    // tile-scaled rescale form: fused multiply-add for 16-bit outputs (their rounding hides the last-ulp difference), the interpreter's
+    // three roundings for fp32 outputs (goldens g4 stay bit-exact); gnk_set_tile_rescale overrides either way
+    p.fused_rescale = c.epi == EPI_TILE && (g_tile_rescale == 2 || (g_tile_rescale == 0 && c.out_dtype != GNK_F32)) ? 1 : 0;
     p.kgroup = c.epi == EPI_TILE && c.QK > GNK_BK ? (int)(c.QK / GNK_BK) : 1;
     if (c.epi == EPI_TILE && c.QK != GNK_BK) {   // Jetfire-style blocks / blocks of several K-steps: the 32-k MFMA instances of the 128 x 128 kernel
         if (op == OP_I8) return gnk_launch_tkb_i8((int)c.QK, la.kmajor, lb.kmajor, p, st);

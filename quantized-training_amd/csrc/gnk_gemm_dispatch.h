@@ -54,7 +54,8 @@ GNK_DECLARE_LAUNCHER(gnk_launch_f8_11_v1);
         switch (epi) {                                                                                      \
         case EPI_PLAIN: return gnk_gemm::launch<GemmCfg<BM, BN, WM, WN, AK, BK, OP, FA, FB, EPI_PLAIN>>(p, st);   \
         case EPI_ROWCOL: return gnk_gemm::launch<GemmCfg<BM, BN, WM, WN, AK, BK, OP, FA, FB, EPI_ROWCOL>>(p, st); \
-        default: return gnk_gemm::launch<GemmCfg<TBM, TBN, TWM, TWN, AK, BK, OP, FA, FB, EPI_TILE>>(p, st);       \
+        default: return p.fused_rescale ? gnk_gemm::launch<GemmCfg<TBM, TBN, TWM, TWN, AK, BK, OP, FA, FB, EPI_TILE, GNK_BK, true>>(p, st)   \
+                                        : gnk_gemm::launch<GemmCfg<TBM, TBN, TWM, TWN, AK, BK, OP, FA, FB, EPI_TILE>>(p, st);            \
         }                                                                                                   \
     }                                                                                                       \
     int NAME(bool a_kmajor, bool b_kmajor, int epi, const GemmParams &p, hipStream_t st) {                  \
@@ -69,7 +70,7 @@ GNK_DECLARE_LAUNCHER(gnk_launch_f8_11_v1);
         switch (epi) {                                                                                      \
         case EPI_PLAIN: return gnk_gemm::launch_pp2<gnk_gemm::PP2Cfg<AK, BK, OP, FA, FB, EPI_PLAIN>>(p, st);   \
         case EPI_ROWCOL: return gnk_gemm::launch_pp2<gnk_gemm::PP2Cfg<AK, BK, OP, FA, FB, EPI_ROWCOL>>(p, st); \
-        default: return gnk_gemm::launch<GemmCfg<128, 128, 2, 2, AK, BK, OP, FA, FB, EPI_TILE>>(p, st);     \
+        default: return gnk_fail(GNK_ERR_UNSUPPORTED, "tile-scaled products run on the 128 x 128 kernels (variant 1)");   \
         }                                                                                                   \
     }                                                                                                       \
     int NAME(bool a_kmajor, bool b_kmajor, int epi, const GemmParams &p, hipStream_t st) {                  \
@@ -83,7 +84,7 @@ GNK_DECLARE_LAUNCHER(gnk_launch_f8_11_v1);
         switch (epi) {                                                                                      \
         case EPI_PLAIN: return gnk_gemm::launch_pp<GemmCfg<256, 256, 2, 4, AK, BK, OP, FA, FB, EPI_PLAIN>>(p, st);   \
         case EPI_ROWCOL: return gnk_gemm::launch_pp<GemmCfg<256, 256, 2, 4, AK, BK, OP, FA, FB, EPI_ROWCOL>>(p, st); \
-        default: return gnk_gemm::launch<GemmCfg<128, 128, 2, 2, AK, BK, OP, FA, FB, EPI_TILE>>(p, st);     \
+        default: return gnk_fail(GNK_ERR_UNSUPPORTED, "tile-scaled products run on the 128 x 128 kernels (variant 1)");   \
         }                                                                                                   \
     }                                                                                                       \
     int NAME(bool a_kmajor, bool b_kmajor, int epi, const GemmParams &p, hipStream_t st) {                  \
@@ -97,7 +98,7 @@ GNK_DECLARE_LAUNCHER(gnk_launch_f8_11_v1);
         switch (epi) {                                                                                      \
         case EPI_PLAIN: return gnk_gemm::launch_w4<gnk_gemm::PP2Cfg<AK, BK, OP, FA, FB, EPI_PLAIN>>(p, st);   \
         case EPI_ROWCOL: return gnk_gemm::launch_w4<gnk_gemm::PP2Cfg<AK, BK, OP, FA, FB, EPI_ROWCOL>>(p, st); \
-        default: return gnk_gemm::launch<GemmCfg<128, 128, 2, 2, AK, BK, OP, FA, FB, EPI_TILE>>(p, st);     \
+        default: return gnk_fail(GNK_ERR_UNSUPPORTED, "tile-scaled products run on the 128 x 128 kernels (variant 1)");   \
         }                                                                                                   \
     }                                                                                                       \
     int NAME(bool a_kmajor, bool b_kmajor, int epi, const GemmParams &p, hipStream_t st) {                  \
@@ -116,15 +117,18 @@ GNK_DECLARE_TKB(gnk_launch_tkb_f8_10);
 GNK_DECLARE_TKB(gnk_launch_tkb_f8_11);
 
 #define GNK_DEFINE_TKB(NAME, OP, FA, FB)                                                                                  \
-    template <int KB> static int NAME##_k(bool ak, bool bk, const GemmParams &p, hipStream_t st) {                        \
-        if (ak) return bk ? gnk_gemm::launch<GemmCfg<128, 128, 2, 2, true, true, OP, FA, FB, EPI_TILE, KB>>(p, st)        \
-                          : gnk_gemm::launch<GemmCfg<128, 128, 2, 2, true, false, OP, FA, FB, EPI_TILE, KB>>(p, st);      \
-        return bk ? gnk_gemm::launch<GemmCfg<128, 128, 2, 2, false, true, OP, FA, FB, EPI_TILE, KB>>(p, st)               \
-                  : gnk_gemm::launch<GemmCfg<128, 128, 2, 2, false, false, OP, FA, FB, EPI_TILE, KB>>(p, st);             \
+    template <int KB, bool FU> static int NAME##_k(bool ak, bool bk, const GemmParams &p, hipStream_t st) {               \
+        if (ak) return bk ? gnk_gemm::launch<GemmCfg<128, 128, 2, 2, true, true, OP, FA, FB, EPI_TILE, KB, FU>>(p, st)    \
+                          : gnk_gemm::launch<GemmCfg<128, 128, 2, 2, true, false, OP, FA, FB, EPI_TILE, KB, FU>>(p, st);  \
+        return bk ? gnk_gemm::launch<GemmCfg<128, 128, 2, 2, false, true, OP, FA, FB, EPI_TILE, KB, FU>>(p, st)           \
+                  : gnk_gemm::launch<GemmCfg<128, 128, 2, 2, false, false, OP, FA, FB, EPI_TILE, KB, FU>>(p, st);         \
+    }                                                                                                                     \
+    template <bool FU> static int NAME##_f(int kb, bool a_kmajor, bool b_kmajor, const GemmParams &p, hipStream_t st) {   \
+        if (kb > 128) return NAME##_k<256, FU>(a_kmajor, b_kmajor, p, st);   /* any multiple of 128: p.kgroup steps per block */  \
+        return kb == 64 ? NAME##_k<64, FU>(a_kmajor, b_kmajor, p, st) : NAME##_k<32, FU>(a_kmajor, b_kmajor, p, st);      \
     }                                                                                                                     \
     int NAME(int kb, bool a_kmajor, bool b_kmajor, const GemmParams &p, hipStream_t st) {                                 \
-        if (kb > 128) return NAME##_k<256>(a_kmajor, b_kmajor, p, st);   /* any multiple of 128: p.kgroup steps per block */  \
-        return kb == 64 ? NAME##_k<64>(a_kmajor, b_kmajor, p, st) : NAME##_k<32>(a_kmajor, b_kmajor, p, st);              \
+        return p.fused_rescale ? NAME##_f<true>(kb, a_kmajor, b_kmajor, p, st) : NAME##_f<false>(kb, a_kmajor, b_kmajor, p, st);  \
     }
 
 // ---------------------------------------------------------------- generic fallback (gnk_gemm_generic.hip)

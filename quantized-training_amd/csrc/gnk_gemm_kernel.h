@@ -44,13 +44,17 @@ struct GemmParams {
     int kgroup;       // tile-scaled with QK = kgroup * 128 (kgroup >= 1; 1 for the 64 / 32-k block kernels): K-steps per scale block
     int64_t kchunk;   // split-K: k elements per split (gridDim.y splits, each writing its own (M, N) int32 slab at C); 0 = no split
     int64_t kchunk0;  // 256 x 256 kernel only: k elements of split 0 when it differs from the others (uneven split); 0 = kchunk
+    int fused_rescale;   // tile-scaled: 1 = acc = fma(f32(part), sA * sB, acc) (tolerance mode), 0 = the reference interpreter's three roundings
     int debug;        // timing-ablation flags (gnk_set_debug_flags): 1 = no LDS-DMA in the main loop, 2 = no MFMA, 4 = no LDS reads
 };
 
 // KB_: k per scale block of the tile-scaled epilogue (128: one block per K-step; 64 / 32: Jetfire-style blocks, 2 / 4 per step;
 // 256 stands for ANY multiple of 128 above 128: GemmParams::kgroup K-steps per block, a run-time number)
-template <int BM_, int BN_, int WM_, int WN_, bool AK_, bool BK_, int OP_, int FA_, int FB_, int EPI_, int KB_ = GNK_BK>
+// FUSED_: tile-scaled rescale as one fma per element with s = sA * sB (GemmParams::fused_rescale; its own instances: as a run-time branch
+// beside the three-rounding form the 256-register kernels spilled 14-20 registers)
+template <int BM_, int BN_, int WM_, int WN_, bool AK_, bool BK_, int OP_, int FA_, int FB_, int EPI_, int KB_ = GNK_BK, bool FUSED_ = false>
 struct GemmCfg {
+    static constexpr bool FUSED = FUSED_;
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, KB = KB_;
     static_assert(KB_ == 128 || ((KB_ == 64 || KB_ == 32 || KB_ == 256) && EPI_ == 2), "scale blocks other than 128 k exist for the tile-scaled epilogue only");
     static constexpr bool A_KMAJOR = AK_, B_KMAJOR = BK_;
@@ -830,21 +834,42 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
                         sbv[j] = *(const GNK_LDS float *)(const GNK_LDS char *)((const char *)panel_b + ((tsi * NB + b) * Cfg::BN + wn * Cfg::WTN + 16 * j + 4 * (lane >> 4)) * 4);
                     else sbv[j] = sbv1[j];
                 }
-                // acc_f32 += (f32(partial) * sA[m/QM, u]) * sB[u, n/QN]   (triton_mm.py:327-331), no FMA
+                // acc_f32 += (f32(partial) * sA[m/QM, u]) * sB[u, n/QN]   (triton_mm.py:327-331)
+                if constexpr (Cfg::FUSED) {
+                    // tolerance mode (16-bit outputs by default, gnk_set_tile_rescale): one multiply per tile and K-block for s = sA * sB, then
+                    // convert + v_fma_f32 per element -- 2 VALU operations per element and block instead of 4 (the VALU stream, not the
+                    // MFMAs, bounds this kernel: DESIGN 6.1a).  An NVIDIA build of the reference contracts its last multiply-add too
+                    // (SURVEY 9.5); parity is the reference's tolerance (benchmark_mm.py:119-121, 144-145), not the interpreter's bits.
 #pragma unroll
-                for (int j = 0; j < NTL; ++j)
+                    for (int j = 0; j < NTL; ++j)
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) {
+                        for (int i = 0; i < MT; ++i) {
+                            const float s = __fmul_rn(sav[i], sbv[j]);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float part;
-                            if constexpr (Cfg::OP == OP_I8) part = (float)acc[i][j][r];
-                            else part = acc[i][j][r];
-                            float tmp = __fmul_rn(part, sav[i]);
-                            tmp = __fmul_rn(tmp, sbv[j]);
-                            accf[i][j][r] = __fadd_rn(accf[i][j][r], tmp);
+                            for (int r = 0; r < 4; ++r) {
+                                float part;
+                                if constexpr (Cfg::OP == OP_I8) part = (float)acc[i][j][r];
+                                else part = acc[i][j][r];
+                                accf[i][j][r] = __builtin_fmaf(part, s, accf[i][j][r]);
+                            }
                         }
-                    }
+                } else {
+                    // the Triton interpreter's form, bit for bit: three separately rounded operations, no FMA
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float part;
+                                if constexpr (Cfg::OP == OP_I8) part = (float)acc[i][j][r];
+                                else part = acc[i][j][r];
+                                float tmp = __fmul_rn(part, sav[i]);
+                                tmp = __fmul_rn(tmp, sbv[j]);
+                                accf[i][j][r] = __fadd_rn(accf[i][j][r], tmp);
+                            }
+                        }
+                }
             }
             if (++c_gph == G) { c_gph = 0; ++c_u; ++c_tsi; }
             if (++c_tk == psteps) { c_tk = 0; c_tsi = 0; ++c_pn; }

@@ -80,6 +80,7 @@ def load() -> ctypes.CDLL:
     L.gnk_last_error.restype = ctypes.c_char_p
     L.gnk_init.restype = ci
     L.gnk_set_gemm_variant.argtypes = [ci]
+    L.gnk_set_tile_rescale.argtypes = [ci]
     L.gnk_quantize_int8.argtypes = [vp, ci, i64, i64, i64, i64, vp, i64, i64, vp, f32, ci, u64, u64, vp, i64, vp]
     L.gnk_quantize_int8_workspace_bytes.argtypes = [i64, i64, i64, i64]
     L.gnk_quantize_int8_workspace_bytes.restype = i64

@@ -184,3 +184,15 @@ def _tile_scaled_mm_hip(A: Tensor, B: Tensor, scale_A: Tensor, scale_B: Tensor):
                                   _cabi.stream_of(A))
     _cabi.check(rc, "tile_scaled_mm")
     return C
+
+
+_TILE_RESCALE_MODES = {"auto": 0, "exact": 1, "fused": 2}
+
+
+def set_tile_rescale(mode: str) -> str:
+    """Rescale form of tile_scaled_mm on the calling thread (include/gnk.h: gnk_set_tile_rescale); returns the previous mode.
+    "auto" (default): fp32 outputs accumulate as the reference's interpreter does, acc += (f32(part) * sA) * sB with three roundings
+    (triton_mm.py:327-331), bf16 / fp16 outputs as acc = fma(f32(part), sA * sB, acc) -- inside the reference's tolerance
+    (benchmark_mm.py:119-121), ~1.4x faster; "exact" / "fused" force one form for every output dtype."""
+    old = _cabi.load().gnk_set_tile_rescale(_TILE_RESCALE_MODES[mode])
+    return {v: k for k, v in _TILE_RESCALE_MODES.items()}[old]

@@ -27,6 +27,28 @@ def dev_layout(x, column_major):
     return to_layout(x.to(DEV), column_major)
 
 
+class tile_rescale:
+    """`with tile_rescale("exact"):` -- the three-rounding rescale of the reference's interpreter for every output dtype (the default uses the
+    fused multiply-add form for bf16 / fp16 outputs: include/gnk.h, gnk_set_tile_rescale)."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        from gn_kernels import mm
+        self.old = mm.set_tile_rescale(self.mode)
+
+    def __exit__(self, *exc):
+        from gn_kernels import mm
+        mm.set_tile_rescale(self.old)
+
+
+def assert_tile_int8_close(got, want32):
+    """The reference's own check of tile-scaled INT8 (benchmark_mm.py:119-121): atol 1e-4, rtol 1e-2 against the fp32 result rounded to the
+    output dtype."""
+    torch.testing.assert_close(got.float().cpu(), want32.to(got.dtype).float().cpu(), atol=1e-4, rtol=1e-2)
+
+
 def fp8_mag(A, B, sa=None, sb=None):
     """sum_k |a_mk * b_kn| (times |scales|): the magnitude the fp8 MFMA's accumulation error scales with."""
     a, b = A.float().abs().cpu(), B.float().abs().cpu()
@@ -92,7 +114,17 @@ def test_tile_scaled_int8_deepseek_golden_bit_exact(layout, variant):
     sB = dev_layout(t_from_bits(g["ds_sB"], torch.bfloat16), bcm).float()
     assert bits_equal(gn_kernels.scaled_mm(A, B, sA, sB), torch.from_numpy(g["ds_C"]))      # fp32 scales -> fp32 out, exact
     sAb, sBb = sA.bfloat16(), sB.bfloat16()
-    assert bits_equal(gn_kernels.scaled_mm(A, B, sAb, sBb), torch.from_numpy(g["ds_C"]).bfloat16())
+    with tile_rescale("exact"):
+        assert bits_equal(gn_kernels.scaled_mm(A, B, sAb, sBb), torch.from_numpy(g["ds_C"]).bfloat16())
+    # default for 16-bit outputs: the fused form, held to the reference's tolerance for this op; forced onto the fp32 output too
+    assert_tile_int8_close(gn_kernels.scaled_mm(A, B, sAb, sBb), torch.from_numpy(g["ds_C"]))
+    if variant != "generic":
+        with tile_rescale("fused"):
+            got = gn_kernels.scaled_mm(A, B, sA, sB)
+        assert_tile_int8_close(got, torch.from_numpy(g["ds_C"]))
+        # ... and it is a different rounding sequence, not the same kernel under another name: some fp32 outputs differ in the last ulps
+        want = torch.from_numpy(g["ds_C"])
+        assert not bits_equal(got, want) and (got.cpu() - want).abs().max() <= 2e-6 * want.abs().max()
 
 
 def test_tile_scaled_int8_jetfire_golden_bit_exact():
@@ -175,7 +207,12 @@ def test_tile_scaled_small_k_blocks_int8_bit_exact(blocks, layout):
     Ad, Bd = dev_layout(A, acm), dev_layout(B, bcm)
     assert bits_equal(gn_kernels.scaled_mm(Ad, Bd, sA.to(DEV), sB.to(DEV)), oracle.scaled_mm(A, B, sA, sB))
     sAh, sBh = sA.bfloat16(), sB.bfloat16()
-    assert bits_equal(gn_kernels.scaled_mm(Ad, Bd, sAh.to(DEV), sBh.to(DEV)), oracle.scaled_mm(A, B, sAh, sBh))
+    want_h = oracle.scaled_mm(A, B, sAh, sBh)
+    with tile_rescale("exact"):
+        assert bits_equal(gn_kernels.scaled_mm(Ad, Bd, sAh.to(DEV), sBh.to(DEV)), want_h)
+    torch.testing.assert_close(gn_kernels.scaled_mm(Ad, Bd, sAh.to(DEV), sBh.to(DEV)).float().cpu(), want_h.float(), atol=1e-4, rtol=1e-2)   # fused (default)
+    with tile_rescale("fused"):
+        torch.testing.assert_close(gn_kernels.scaled_mm(Ad, Bd, sA.to(DEV), sB.to(DEV)).cpu(), oracle.scaled_mm(A, B, sA, sB), atol=1e-4, rtol=1e-2)
     sAt = sA.T.contiguous().T                                                    # column-major sA, as benchmark_mm.py:91-96 lays it out
     assert bits_equal(gn_kernels.scaled_mm(Ad, Bd, sAt.to(DEV).T.contiguous().T, sB.to(DEV)), oracle.scaled_mm(A, B, sA, sB))
 
@@ -337,10 +374,17 @@ def test_full_size_4096_tile_scaled_and_fp8():
     B = to_layout(torch.randint(-128, 127, (S, S), dtype=torch.int8, device=DEV), True)
     tsA = torch.randn(S, S // 128, device=DEV).div(128).bfloat16()
     tsB = to_layout(torch.randn(S // 128, S // 128, device=DEV).div(128).bfloat16(), True)
-    out = gn_kernels.scaled_mm(A, B, tsA, tsB)
+    with tile_rescale("exact"):
+        out = gn_kernels.scaled_mm(A, B, tsA, tsB)
     rows = torch.arange(0, S, 97, device=DEV)
     want = oracle.scaled_mm(A[rows].cpu().contiguous(), B[:, :256].cpu(), tsA[rows].cpu().contiguous(), tsB[:, :2].cpu())
     assert bits_equal(out[rows][:, :256], want)
+    # the default (fused) form for bf16 outputs: the reference's check of this op (benchmark_mm.py:119-121) against scaled_mm_ref, everywhere
+    outf = gn_kernels.scaled_mm(A, B, tsA, tsB)
+    ref = _scaled_ref(A, B, tsA, tsB).bfloat16()
+    torch.testing.assert_close(outf, ref, atol=1e-4, rtol=1e-2)
+    torch.testing.assert_close(outf[rows][:, :256].cpu(), want, atol=1e-4, rtol=1e-2)
+    assert (outf != out).float().mean().item() < 0.05      # the two forms differ by a bf16 ulp in a few percent of the outputs at most
     A8 = torch.randn(S, S, device=DEV).to(torch.float8_e4m3fn)
     B8 = to_layout(torch.randn(S, S, device=DEV).to(torch.float8_e4m3fn), True)
     rs = torch.randn(S, 1, device=DEV).div(128).bfloat16()
@@ -372,6 +416,7 @@ def test_full_size_4096_jetfire_blocks(layout):
     assert torch.equal(gn_kernels.scaled_mm(A, B, sA * 2, sB), out * 2)        # power-of-two scaling commutes with every rounding
     outh = gn_kernels.scaled_mm(A, B, sA.bfloat16(), sB.bfloat16())
     assert outh.dtype is torch.bfloat16 and torch.isfinite(outh.float()).all()
+    torch.testing.assert_close(outh, _scaled_ref(A, B, sA.bfloat16(), sB.bfloat16()).bfloat16(), atol=1e-4, rtol=1e-2)   # fused form, benchmark_mm.py:119-121
 
 
 # ------------------------------------------------------------------------------- round-2 parity gaps
@@ -488,8 +533,10 @@ def test_auto_dispatch_at_benchmark_mid_sizes(S, layout):
     assert bits_equal(out[rows], oracle.scaled_mm(A[rows].cpu().contiguous(), B.cpu(), rs[rows].cpu().contiguous(), cs.cpu()))
     tsA = to_layout(torch.randn(S, S // 128, device=DEV).div(128).bfloat16(), acm)
     tsB = to_layout(torch.randn(S // 128, S // 128, device=DEV).div(128).bfloat16(), bcm)
-    outt = gn_kernels.scaled_mm(A, B, tsA, tsB)
-    assert bits_equal(outt[rows], oracle.scaled_mm(A[rows].cpu().contiguous(), B.cpu(), tsA[rows].cpu().contiguous(), tsB.cpu()))
+    want_t = oracle.scaled_mm(A[rows].cpu().contiguous(), B.cpu(), tsA[rows].cpu().contiguous(), tsB.cpu())
+    with tile_rescale("exact"):
+        assert bits_equal(gn_kernels.scaled_mm(A, B, tsA, tsB)[rows], want_t)
+    torch.testing.assert_close(gn_kernels.scaled_mm(A, B, tsA, tsB)[rows].cpu(), want_t, atol=1e-4, rtol=1e-2)
     A8 = to_layout(torch.randn(S, S, device=DEV).to(torch.float8_e4m3fn), acm)
     B8 = to_layout(torch.randn(S, S, device=DEV).to(torch.float8_e4m3fn), bcm)
     out8 = gn_kernels.scaled_mm(A8, B8, rs, cs)
