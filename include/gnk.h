@@ -247,9 +247,11 @@ int gnk_set_tile_rescale(int mode);
  * eager ATen and allocates freely.  Same arguments and results as gnk_quantize_int8, bit for bit, minus the workspace:
  * the fp32 absmax words a strided reduction needs between its two kernels live in a GNK_NOALLOC_SCRATCH_BYTES buffer
  * inside the library's code object (one copy per GPU, held until the process ends).  The call performs no hipMalloc /
- * hipFree and calls no allocating routine.  Limits: a strided reduction (sxc != 1) over more than
- * gnk_quantize_int8_noalloc_max_rows() = GNK_NOALLOC_SCRATCH_BYTES / 4 logical rows is rejected with
- * GNK_ERR_UNSUPPORTED; calls that overlap on one GPU (different streams or threads) share the buffer and RACE --
+ * hipFree and calls no allocating routine.  Limits: an input that takes the strided-reduction kernels (sxr == 1, rows a multiple of the
+ * vector width, aligned: the same test gnk_quantize_int8 applies) over more than gnk_quantize_int8_noalloc_max_rows() =
+ * GNK_NOALLOC_SCRATCH_BYTES / 4 logical rows is rejected with GNK_ERR_UNSUPPORTED (inputs the generic kernel takes need no scratch and
+ * are never rejected for their size).  Under HIP graph capture: call gnk_init() once per device BEFORE the capture begins -- the first
+ * call on a device runs hipGetDeviceCount / hipDeviceGetAttribute / hipGetSymbolAddress, which are not capturable.  Calls that overlap on one GPU (different streams or threads) share the buffer and RACE --
  * serialise them, or use gnk_quantize_int8 with one workspace per stream.  Every word a call reads it has written
  * (partial maxima) or cleared on `stream` (reductions too large for the buffer to hold partial rows) first.
  */

@@ -99,8 +99,9 @@ struct OperandLayout {
 OperandLayout classify(const void *ptr, int64_t ext, int64_t K, int64_t s_mn, int64_t s_k) {
     OperandLayout o = {false, true, 0};
     if (((uintptr_t)ptr & 15) != 0) return o;
-    // K-major: every row is a contiguous K-vector starting at a 16-byte boundary
-    if (s_k == 1 && (ext == 1 || (s_mn % 16 == 0 && s_mn >= K))) {
+    // K-major: every row is a contiguous K-vector starting at a 16-byte boundary.  A single row (ext == 1) has no pitch to round K up to:
+    // the K-tail stager fetches whole 16-byte chunks, so K itself must be a multiple of 16 there (else the generic kernel takes the call)
+    if (s_k == 1 && (ext == 1 ? K % 16 == 0 : (s_mn % 16 == 0 && s_mn >= K))) {
         o.fast = true; o.kmajor = true; o.ld = ext == 1 ? K : s_mn;
         return o;
     }

@@ -41,6 +41,12 @@ struct MxParams {
 constexpr int FMT_FP4 = 4;        // cbsz / blgp code of e2m1
 constexpr int MX_LDS = MxCfg::LDS_BYTES + 2 * 128 * 64;   // operand buffers + the scale panel: 80 KiB, two workgroups per CU
 
+// E8M0 scale byte -> fp32 as the OCP MX spec (and the MFMA's scale input) reads it: 2^(s - 127); s == 0 is 2^-127 (an fp32 subnormal, not 0)
+// and s == 255 is NaN.
+__device__ __forceinline__ float gnk_e8m0_to_f32(unsigned char s) {
+    return s == 255 ? __uint_as_float(0x7fc00000u) : s == 0 ? __uint_as_float(0x00400000u) : __uint_as_float((unsigned)s << 23);
+}
+
 // BPS = MX blocks per 128-byte K-step: 8 = FP4 (256 k, two MFMAs per tile and step, FA = FB = 4), 4 = FP8 (128 k, one MFMA; FA / FB =
 // 0 e4m3, 1 e5m2).  The scale panel holds 64 bytes per operand row either way: 8 (FP4) or 16 (FP8) K-steps.
 template <int BPS, int FA, int FB>
@@ -515,7 +521,7 @@ __global__ void __launch_bounds__(256) mxfp4_generic_kernel(const MxParams mp) {
             part += gnk_fp4_to_f32(ca & 15) * gnk_fp4_to_f32(cb & 15);
             part += gnk_fp4_to_f32(ca >> 4) * gnk_fp4_to_f32(cb >> 4);
         }
-        const float s = __uint_as_float((unsigned)mp.sa[m * mp.ldsa + kb] << 23) * __uint_as_float((unsigned)mp.sb[n * mp.ldsb + kb] << 23);
+        const float s = gnk_e8m0_to_f32(mp.sa[m * mp.ldsa + kb]) * gnk_e8m0_to_f32(mp.sb[n * mp.ldsb + kb]);
         acc += part * s;
     }
     if (mp.bias) acc += gnk_load_scalar_rt(mp.bias, mp.bias_dtype, n);
@@ -546,7 +552,7 @@ __global__ void __launch_bounds__(256) mxfp8_generic_kernel(const MxParams mp, i
     for (int64_t kb = 0; kb < nblk; ++kb) {
         float part = 0.f;
         for (int e = 0; e < 32; ++e) part += mx_f8_to_f32(a[kb * 32 + e], a_e5m2) * mx_f8_to_f32(b[kb * 32 + e], b_e5m2);
-        const float s = __uint_as_float((unsigned)mp.sa[m * mp.ldsa + kb] << 23) * __uint_as_float((unsigned)mp.sb[n * mp.ldsb + kb] << 23);
+        const float s = gnk_e8m0_to_f32(mp.sa[m * mp.ldsa + kb]) * gnk_e8m0_to_f32(mp.sb[n * mp.ldsb + kb]);
         acc += part * s;
     }
     if (mp.bias) acc += gnk_load_scalar_rt(mp.bias, mp.bias_dtype, n);

@@ -702,6 +702,15 @@ int launch_colwise_given(const void *x, int8_t *q, void *scale, int64_t P, int64
 
 inline bool aligned(const void *p, int a) { return ((uintptr_t)p % a) == 0; }
 
+// the strided-reduction kernels (the only ones that need the workspace) take the call: shared by gnk_quantize_int8 and its no-alloc form
+inline bool colwise_fast_path(const void *x, int x_dtype, int64_t R, int64_t C, int64_t sxr, int64_t sxc, const void *q, int64_t sqr, int64_t sqc) {
+    const int esz = gnk_dtype_size(x_dtype), vec = 16 / esz;
+    const bool rowwise = C > 0 && sxc == 1 && sqc == 1 && C % vec == 0 && aligned(x, 16) && (sxr * esz) % 16 == 0 && aligned(q, vec) &&
+                         sqr % vec == 0 && sxr >= C && sqr >= C;
+    return !rowwise && C > 0 && sxr == 1 && sqr == 1 && R % vec == 0 && aligned(x, 16) && (sxc * esz) % 16 == 0 && aligned(q, vec) &&
+           sqc % vec == 0 && sxc >= R && sqc >= R;
+}
+
 }  // namespace
 
 // Strided reduction: the workspace asked for holds the partial maxima of pass 1 (<= GNK_COL_PARTS rows of R words: nothing to clear);
@@ -741,8 +750,7 @@ extern "C" int gnk_quantize_int8(const void *x, int x_dtype, int64_t R, int64_t 
         GNK_DISPATCH(launch_rowwise, x, q, scale, R, C, sxr, sqr, eps, seed, offset, st);
     }
     // reduction along the strided dim: memory is [P = C][Q = R] with Q contiguous
-    if (C > 0 && sxr == 1 && sqr == 1 && R % vec == 0 && aligned(x, 16) && (sxc * esz) % 16 == 0 && aligned(q, vec) &&
-        sqc % vec == 0 && sxc >= R && sqc >= R) {
+    if (colwise_fast_path(x, x_dtype, R, C, sxr, sxc, q, sqr, sqc)) {
         if (!workspace || workspace_bytes < R * 4)
             return gnk_fail(GNK_ERR_WORKSPACE, "quantize_int8: strided reduction needs a workspace of %lld bytes", (long long)(R * 4));
         GNK_DISPATCH(launch_colwise, x, q, scale, /*P=*/C, /*Q=*/R, /*ld=*/sxc, /*ldq=*/sqc, eps, seed, offset,
@@ -790,7 +798,8 @@ extern "C" int64_t gnk_quantize_int8_noalloc_max_rows(void) { return GNK_NOALLOC
 extern "C" int gnk_quantize_int8_noalloc(const void *x, int x_dtype, int64_t R, int64_t C, int64_t sxr, int64_t sxc,
                                          int8_t *q, int64_t sqr, int64_t sqc, void *scale, float eps, int sr, uint64_t seed,
                                          uint64_t offset, void *stream) {
-    const int64_t need = (sxc == 1 || R <= 0 || sxr != 1) ? 0 : R * 4;   // the minimum gnk_quantize_int8 accepts (one word per logical row)
+    // only the strided-reduction kernels use the scratch (one word per logical row); every other input goes through untouched
+    const int64_t need = gnk_is_float_dtype(x_dtype) && colwise_fast_path(x, x_dtype, R, C, sxr, sxc, q, sqr, sqc) ? R * 4 : 0;
     if (need > (int64_t)GNK_NOALLOC_SCRATCH_BYTES)
         return gnk_fail(GNK_ERR_UNSUPPORTED, "quantize_int8_noalloc: a strided reduction over %lld logical rows needs %lld bytes of scratch, "
                         "the built-in buffer holds %lld (at most %lld rows): use gnk_quantize_int8 with a caller workspace",

@@ -145,7 +145,8 @@ _CACHE_SLOTS = 8                      # int8 copies alive at once (LRU); q/k/v a
 _cache_enabled = True
 _fused_enabled = True
 _cache: dict = {}                     # id(source) -> [weakref(source), version, {kind: value}]
-_cache_lock = threading.Lock()        # forward runs on the caller's thread, backward on the autograd engine's
+_cache_lock = threading.RLock()       # forward runs on the caller's thread, backward on the autograd engine's; re-entrant: a GC pass inside
+                                      # _cache_put can finalize a cached source tensor, whose weakref callback (_gone) takes the lock on the same thread
 
 
 def set_quantize_plan(*, cache: bool | None = None, fused: bool | None = None) -> tuple[bool, bool]:

@@ -661,3 +661,20 @@ def test_split_k_on_the_256_kernel_is_bit_identical(layout, N, slabs):
         L.gnk_set_gemm_variant(old)
     assert torch.equal(got.view(torch.int16), want.view(torch.int16))
     assert torch.equal(got_t.view(torch.int16), want.T.contiguous().view(torch.int16))
+
+
+def test_single_row_operand_with_unpadded_k_tail_stays_inside_its_buffer():
+    """an operand with one row (M == 1 or N == 1) has no pitch to round K up to, so with K % 16 != 0 the K-tail stager's 16-byte
+    chunk would read past the end of an exact-size buffer.  Such calls take the generic kernel.  The operands sit at the very end of their
+    allocations (a raw C-ABI caller could have a page edge there); results against the oracle."""
+    g = torch.Generator().manual_seed(7)
+    for M, N, K in ((1, 7, 100), (5, 1, 100), (1, 1, 33)):
+        A = torch.randint(-128, 128, (M, K), dtype=torch.int8, generator=g)
+        B = torch.randint(-128, 128, (K, N), dtype=torch.int8, generator=g)
+        rs, cs = torch.rand(M, 1, generator=g) + 0.5, torch.rand(1, N, generator=g) + 0.5
+        bufA = torch.empty(4096 + M * K, dtype=torch.int8, device=DEV)
+        Ad = bufA[4096:].view(M, K).copy_(A)                       # ends exactly at the end of the allocation's requested size
+        bufB = torch.empty(4096 + K * N, dtype=torch.int8, device=DEV)
+        Bd = bufB[4096:].view(N, K).copy_(B.T).T                    # column-major (K contiguous), same placement
+        assert torch.equal(gn_kernels.int8_mm(Ad, Bd).cpu(), oracle.int8_mm(A, B.T.contiguous().T))
+        assert bits_equal(gn_kernels.scaled_mm(Ad, Bd, rs.to(DEV), cs.to(DEV)), oracle.scaled_mm(A, B.T.contiguous().T, rs, cs))
