@@ -193,6 +193,40 @@ def vendor_yardstick(cases, S):
     return out
 
 
+def vendor_yardstick_small(dev):
+    """the same-box library yardsticks at the sizes where fixed costs dominate -- 1024^3, 2048^3 and the five GEMM
+    shapes of a Llama-2-470m step (8192 tokens; M x N x K) -- A row-major, B column-major (the layout hipBLASLt's int8 / fp8 paths take),
+    every entry HIP-graph-replayed (no host launch path on either side).  TOPS per entry; `ours / vendor` for the int8 pair."""
+    import gn_kernels
+
+    out = {}
+    shapes = [(1024, 1024, 1024), (2048, 2048, 2048), (8192, 1024, 1024), (8192, 4096, 1024), (8192, 1024, 4096), (1024, 1024, 8192), (1024, 4096, 8192)]
+    for M, N, K in shapes:
+        A = torch.randint(-128, 127, (M, K), dtype=torch.int8, device=dev)
+        B = torch.randint(-128, 127, (N, K), dtype=torch.int8, device=dev).T
+        A8, B8 = torch.randn(M, K, device=dev).to(torch.float8_e4m3fn), torch.randn(N, K, device=dev).to(torch.float8_e4m3fn).T
+        Ab, Bb = torch.randn(M, K, device=dev).bfloat16(), torch.randn(N, K, device=dev).bfloat16().T
+        sa, sb = torch.randn(M, 1, device=dev).div(128).bfloat16(), torch.randn(1, N, device=dev).div(128).bfloat16()
+        ra, cb = sa.float(), sb.float()
+        row = {}
+        for name, fn in (("ours int8_mm -> int32", lambda: gn_kernels.int8_mm(A, B)),
+                         ("vendor torch._int_mm -> int32", lambda: torch._int_mm(A, B)),
+                         ("ours scaled_mm int8 -> bf16", lambda: gn_kernels.scaled_mm(A, B, sa, sb)),
+                         ("ours scaled_mm fp8 -> bf16", lambda: gn_kernels.scaled_mm(A8, B8, sa, sb)),
+                         ("vendor torch._scaled_mm fp8 rowwise -> bf16", lambda: torch._scaled_mm(A8, B8, scale_a=ra, scale_b=cb, out_dtype=torch.bfloat16)),
+                         ("vendor torch.mm bf16", lambda: torch.mm(Ab, Bb))):
+            try:
+                med = time_kernel_graph(fn, per_graph=20, replays=5)
+                row[name] = round(2 * M * N * K / (med * 1e-3) * 1e-12, 1)
+            except Exception as exc:
+                row[name] = f"refused: {type(exc).__name__}: {str(exc)[:80]}"
+        a, b = row.get("ours int8_mm -> int32"), row.get("vendor torch._int_mm -> int32")
+        if isinstance(a, float) and isinstance(b, float):
+            row["ours / vendor (int8 -> int32)"] = round(a / b, 3)
+        out[f"{M}x{N}x{K}"] = row
+    return out
+
+
 TRAIN_DETAIL_BUDGET_S = 420   # no new training run is started after this many seconds of detail_train
 
 
@@ -435,6 +469,10 @@ def main():
                 nxt["error"] = f"{type(exc).__name__}: {exc}"
             out["detail_next_rows"] = nxt
             out["detail_vendor_yardstick_4096_tops"] = vendor_yardstick(cases, S)
+            try:
+                out["detail_vendor_yardstick_small_tops_hipgraph_replay"] = vendor_yardstick_small(dev)
+            except Exception as exc:   # detail only
+                out["detail_vendor_yardstick_small_tops_hipgraph_replay"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()
     del cases

@@ -50,8 +50,10 @@ def _int8_mm_hip(A: Tensor, B: Tensor):
 
 def _triton_mm(A: Tensor, B: Tensor, out_dtype: torch.dtype | None = None, acc_dtype: torch.dtype | None = None):
     """Unscaled matmul entry kept under the reference's name (triton_mm.py:131-143) for
-    benchmark_mm.py: int8 -> int32 and fp8 -> out_dtype go to the MFMA kernels.  The
-    fp16-accumulate variant benchmarked by the reference is outside the INT8/FP8 hot path."""
+    benchmark_mm.py: int8 -> int32 and fp8 -> out_dtype go to the MFMA kernels.  16- / 32-bit float operands (benchmark_mm.py:110, an
+    unchecked timing row outside the INT8/FP8 hot path) are a plain library GEMM: torch.mm (hipBLASLt / rocBLAS) with fp32 accumulation
+    -- `acc_dtype=torch.float16` is accepted and accumulates in fp32 too (CDNA4 has no fp16-accumulating MFMA), which is at least as
+    accurate as the reference's fp16 accumulator; the result is cast to `out_dtype` (default: A's dtype, triton_mm.py:132)."""
     assert A.shape[1] == B.shape[0]
     if A.dtype is torch.int8 and B.dtype is torch.int8 and out_dtype in (None, torch.int32) and acc_dtype in (None, torch.int32):
         if out_dtype is None:
@@ -61,6 +63,8 @@ def _triton_mm(A: Tensor, B: Tensor, out_dtype: torch.dtype | None = None, acc_d
         from .fp8 import _fp8_mm_any
 
         return _fp8_mm_any(A, B, out_dtype or torch.bfloat16)
+    if A.dtype in (torch.float16, torch.bfloat16, torch.float32) and B.dtype is A.dtype and acc_dtype in (None, torch.float32, torch.float16):
+        return torch.mm(A, B).to(out_dtype or A.dtype)
     raise NotImplementedError(f"_triton_mm({A.dtype}, {B.dtype}, out={out_dtype}, acc={acc_dtype}) is outside the INT8/FP8 hot path")
 
 

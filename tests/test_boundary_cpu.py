@@ -131,3 +131,16 @@ def test_product_sources_never_touch_the_oracle():
             assert not re.search(r"^\s*(import|from)\s+oracle\b", text, flags=re.M), path        # Python imports
             assert not re.search(r"#\s*include\s+[\"<][^\n]*oracle", text), path                # C/C++ includes
             assert "libgnk_oracle" not in text and "CDLL(" not in text.replace("ctypes.CDLL(str(_LIB_PATH))", ""), path
+
+
+def test_triton_mm_with_float_operands_is_a_plain_library_gemm():
+    """reference triton_mm.py:131-143 / benchmark_mm.py:110: `_triton_mm(A_f16, B_f16, acc_dtype=torch.float16)`, an unchecked timing row.
+    Here: torch.mm with fp32 accumulation, cast to out_dtype (default A's dtype)."""
+    g = torch.Generator().manual_seed(0)
+    A, B = torch.randn(32, 64, generator=g).bfloat16(), torch.randn(64, 48, generator=g).bfloat16()
+    out = gn_kernels._triton_mm(A, B, acc_dtype=torch.float16)
+    assert out.dtype is torch.bfloat16 and out.shape == (32, 48)
+    torch.testing.assert_close(out.float(), A.float() @ B.float(), atol=0.25, rtol=2e-2)
+    assert gn_kernels._triton_mm(A.float(), B.float(), out_dtype=torch.bfloat16).dtype is torch.bfloat16
+    with pytest.raises(NotImplementedError):
+        gn_kernels._triton_mm(A, B.float())
