@@ -248,7 +248,7 @@ template <int DT> struct GnkAbsMax {
 };
 
 // 16-byte store of a finished output tile row segment.  GNK_STORE_MODE (experiment, tools/store_mode_ab.sh): 0 plain write-back store;
-// 1 non-temporal; 2 sc1 (agent scope: written through the XCD's L2); 3 sc0 sc1 (system scope); 4 sc1 nt.
+// 1 non-temporal; 2 sc1 (agent scope: written through the XCD's L2); 3 sc0 sc1 (system scope); 4 sc1 nt; 5 no store (timing ablation).
 #ifndef GNK_STORE_MODE
 #define GNK_STORE_MODE 0
 #endif
@@ -261,7 +261,9 @@ __device__ __forceinline__ void gnk_store16_out(void *ptr, const v4i &d) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(ptr), "v"(d) : "memory");
 #elif GNK_STORE_MODE == 3
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(ptr), "v"(d) : "memory");
-#else
+#elif GNK_STORE_MODE == 4
     asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(ptr), "v"(d) : "memory");
+#else   // 5: timing ablation -- no store at all (results WRONG): what the output write costs a launch, tail included
+    asm volatile("" : : "v"(ptr), "v"(d));
 #endif
 }

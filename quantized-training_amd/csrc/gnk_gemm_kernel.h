@@ -388,10 +388,11 @@ template <class Cfg> struct EpiScales {
             else load_t<GNK_F32>(p, mrow, ncol);
         }
     }
-    // ORDER 0: (acc * row) * col (triton_mm.py:207-212); 1: (acc * col) * row (the CUTLASS-named ops); -1: p.order at run time.
-    // The staged epilogues resolve it once per kernel (a per-element select computes both products: 4 multiplies and a
-    // v_cndmask per output where 2 multiplies do).
-    template <int ORDER = -1, class AccT_>
+    // ORDER 0: (acc * row) * col (triton_mm.py:207-212); 1: (acc * col) * row (the CUTLASS-named ops).  Every epilogue resolves p.order
+    // ONCE, at its entry, into one of two instances: a per-element `p.order == 0 ? ... : ...` made the compiler select between the
+    // ADDRESSES of rs[] / cs[] elements, which kept both arrays in scratch memory -- 84-100 bytes of private segment per lane in every
+    // row/col-scaled kernel of rounds 1-2, and with it the scratch set-up of every such dispatch.
+    template <int ORDER, class AccT_>
     __device__ __forceinline__ float value(const GemmParams &p, const AccT_ &acc, const v4f *accf, int i, int j, int r) const {
         if constexpr (Cfg::EPI == EPI_TILE) return (*accf)[r];
         float a;
@@ -399,13 +400,13 @@ template <class Cfg> struct EpiScales {
         else a = acc[r];
         if constexpr (Cfg::EPI == EPI_PLAIN) return a;
         if constexpr (ORDER == 0) return __fmul_rn(__fmul_rn(a, rs[i]), cs[j][r]);
-        if constexpr (ORDER == 1) return __fmul_rn(__fmul_rn(a, cs[j][r]), rs[i]);
-        return p.order == 0 ? __fmul_rn(__fmul_rn(a, rs[i]), cs[j][r]) : __fmul_rn(__fmul_rn(a, cs[j][r]), rs[i]);
+        static_assert(ORDER == 0 || ORDER == 1, "multiply order is a compile-time choice");
+        return __fmul_rn(__fmul_rn(a, cs[j][r]), rs[i]);
     }
 };
 
 // Final values of one lane -> memory.  For OUT == GNK_I32 the floats carry int32 bit patterns.
-template <class Cfg, int OUT, bool VEC>
+template <class Cfg, int OUT, bool VEC, int ORDER = 0>
 __device__ __forceinline__ void epilogue(const GemmParams &p, typename AccT<Cfg::OP>::type (&acc)[Cfg::MT][Cfg::NTL],
                                          v4f (*accf)[Cfg::EPI == EPI_TILE ? Cfg::NTL : 1], int64_t mrow, int64_t ncol,
                                          const float *lsc = nullptr, int mloc = 0, int nloc = 0) {
@@ -430,7 +431,7 @@ __device__ __forceinline__ void epilogue(const GemmParams &p, typename AccT<Cfg:
             for (int i = 0; i < MT; ++i) {
                 float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = sc.value(p, acc[i][j], nullptr, i, j, r);
+                for (int r = 0; r < 4; ++r) v[r] = sc.template value<ORDER>(p, acc[i][j], nullptr, i, j, r);
                 store4<OUT, VEC>(p.C, mrow + 16 * i, ncol + 16 * j, p.M, p.N, v[0], v[1], v[2], v[3]);
             }
     } else {
@@ -448,7 +449,7 @@ __device__ __forceinline__ void epilogue(const GemmParams &p, typename AccT<Cfg:
 // 32 B per row and instruction measured 1.6 TB/s; whole-line stores run at the HBM write rate.
 // LDS image per wave: [WTM rows][128 B], 16-byte chunk c of row m kept at c ^ (m & 7) (conflict-free
 // ds_read_b128, 2-way ds_write_b64).
-template <class Cfg, int OUT, int ORDER = -1>
+template <class Cfg, int OUT, int ORDER = 0>
 __device__ __forceinline__ void epilogue_lds(const GemmParams &p, typename AccT<Cfg::OP>::type (&acc)[Cfg::MT][Cfg::NTL],
                                              v4f (*accf)[Cfg::EPI == EPI_TILE ? Cfg::NTL : 1], char *smem, int wave, int lane,
                                              int64_t mwave, int64_t nwave, const float *lsc = nullptr, int mlw = 0, int nlw = 0) {
@@ -524,18 +525,18 @@ __device__ __forceinline__ void run_epilogue(const GemmParams &p, typename AccT<
                 if (Cfg::EPI != EPI_ROWCOL || p.order == 0) epilogue_lds<Cfg, GNK_BF16, 0>(p, acc, accf, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
                 else epilogue_lds<Cfg, GNK_BF16, 1>(p, acc, accf, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
             }
-            else if (vec_ok) epilogue<Cfg, GNK_BF16, true>(p, acc, accf, mrow, ncol, lsc, mloc, nloc);
-            else epilogue<Cfg, GNK_BF16, false>(p, acc, accf, mrow, ncol, lsc, mloc, nloc);
+            else if (vec_ok) { if (Cfg::EPI != EPI_ROWCOL || p.order == 0) epilogue<Cfg, GNK_BF16, true, 0>(p, acc, accf, mrow, ncol, lsc, mloc, nloc); else epilogue<Cfg, GNK_BF16, true, 1>(p, acc, accf, mrow, ncol, lsc, mloc, nloc); }
+            else { if (Cfg::EPI != EPI_ROWCOL || p.order == 0) epilogue<Cfg, GNK_BF16, false, 0>(p, acc, accf, mrow, ncol, lsc, mloc, nloc); else epilogue<Cfg, GNK_BF16, false, 1>(p, acc, accf, mrow, ncol, lsc, mloc, nloc); }
         } else if (p.out_dtype == GNK_F16) {
             if (lds_ok) {
                 if (Cfg::EPI != EPI_ROWCOL || p.order == 0) epilogue_lds<Cfg, GNK_F16, 0>(p, acc, accf, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
                 else epilogue_lds<Cfg, GNK_F16, 1>(p, acc, accf, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
             }
-            else if (vec_ok) epilogue<Cfg, GNK_F16, true>(p, acc, accf, mrow, ncol, lsc, mloc, nloc);
-            else epilogue<Cfg, GNK_F16, false>(p, acc, accf, mrow, ncol, lsc, mloc, nloc);
+            else if (vec_ok) { if (Cfg::EPI != EPI_ROWCOL || p.order == 0) epilogue<Cfg, GNK_F16, true, 0>(p, acc, accf, mrow, ncol, lsc, mloc, nloc); else epilogue<Cfg, GNK_F16, true, 1>(p, acc, accf, mrow, ncol, lsc, mloc, nloc); }
+            else { if (Cfg::EPI != EPI_ROWCOL || p.order == 0) epilogue<Cfg, GNK_F16, false, 0>(p, acc, accf, mrow, ncol, lsc, mloc, nloc); else epilogue<Cfg, GNK_F16, false, 1>(p, acc, accf, mrow, ncol, lsc, mloc, nloc); }
         } else {
-            if (vec_ok) epilogue<Cfg, GNK_F32, true>(p, acc, accf, mrow, ncol, lsc, mloc, nloc);
-            else epilogue<Cfg, GNK_F32, false>(p, acc, accf, mrow, ncol, lsc, mloc, nloc);
+            if (vec_ok) { if (Cfg::EPI != EPI_ROWCOL || p.order == 0) epilogue<Cfg, GNK_F32, true, 0>(p, acc, accf, mrow, ncol, lsc, mloc, nloc); else epilogue<Cfg, GNK_F32, true, 1>(p, acc, accf, mrow, ncol, lsc, mloc, nloc); }
+            else { if (Cfg::EPI != EPI_ROWCOL || p.order == 0) epilogue<Cfg, GNK_F32, false, 0>(p, acc, accf, mrow, ncol, lsc, mloc, nloc); else epilogue<Cfg, GNK_F32, false, 1>(p, acc, accf, mrow, ncol, lsc, mloc, nloc); }
         }
     }
 }

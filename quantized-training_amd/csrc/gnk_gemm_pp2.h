@@ -195,11 +195,11 @@ template <class Cfg> struct PP2F8 {
         else x = a[reg];
         if constexpr (Cfg::EPI == EPI_PLAIN) return x;
         if constexpr (ORDER == 0) return __fmul_rn(__fmul_rn(x, rs), cs);
-        if constexpr (ORDER == 1) return __fmul_rn(__fmul_rn(x, cs), rs);
-        return p.order == 0 ? __fmul_rn(__fmul_rn(x, rs), cs) : __fmul_rn(__fmul_rn(x, cs), rs);
+        static_assert(ORDER == 0 || ORDER == 1, "multiply order is a compile-time choice (EpiScales::value)");
+        return __fmul_rn(__fmul_rn(x, cs), rs);
     }
 
-    template <int OUT, int MODE, int ORDER = -1>   // ORDER: multiply order resolved at compile time (see EpiScales::value)   // MODE 0: LDS-staged 16-byte stores (2-byte outputs); 1: direct vector; 2: direct scalar
+    template <int OUT, int MODE, int ORDER = 0>   // ORDER: multiply order resolved at compile time (see EpiScales::value)   // MODE 0: LDS-staged 16-byte stores (2-byte outputs); 1: direct vector; 2: direct scalar
     static __device__ __forceinline__ void epilogue(const GemmParams &p, acc_t (&acc)[4][2], char *smem, int wave, int lane, int64_t mwave, int64_t nwave,
                                                     const float *lsc, int mlw, int nlw) {
         float rs[4], cs[2][4][4];
@@ -272,18 +272,18 @@ template <class Cfg> struct PP2F8 {
                 if (Cfg::EPI != EPI_ROWCOL || p.order == 0) epilogue<GNK_BF16, 0, 0>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
                 else epilogue<GNK_BF16, 0, 1>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
             }
-            else if (vec_ok) epilogue<GNK_BF16, 1>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
-            else epilogue<GNK_BF16, 2>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
+            else if (vec_ok) { if (Cfg::EPI != EPI_ROWCOL || p.order == 0) epilogue<GNK_BF16, 1, 0>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw); else epilogue<GNK_BF16, 1, 1>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw); }
+            else { if (Cfg::EPI != EPI_ROWCOL || p.order == 0) epilogue<GNK_BF16, 2, 0>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw); else epilogue<GNK_BF16, 2, 1>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw); }
         } else if (p.out_dtype == GNK_F16) {
             if (lds_ok) {
                 if (Cfg::EPI != EPI_ROWCOL || p.order == 0) epilogue<GNK_F16, 0, 0>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
                 else epilogue<GNK_F16, 0, 1>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
             }
-            else if (vec_ok) epilogue<GNK_F16, 1>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
-            else epilogue<GNK_F16, 2>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
+            else if (vec_ok) { if (Cfg::EPI != EPI_ROWCOL || p.order == 0) epilogue<GNK_F16, 1, 0>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw); else epilogue<GNK_F16, 1, 1>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw); }
+            else { if (Cfg::EPI != EPI_ROWCOL || p.order == 0) epilogue<GNK_F16, 2, 0>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw); else epilogue<GNK_F16, 2, 1>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw); }
         } else {
-            if (vec_ok) epilogue<GNK_F32, 1>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
-            else epilogue<GNK_F32, 2>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw);
+            if (vec_ok) { if (Cfg::EPI != EPI_ROWCOL || p.order == 0) epilogue<GNK_F32, 1, 0>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw); else epilogue<GNK_F32, 1, 1>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw); }
+            else { if (Cfg::EPI != EPI_ROWCOL || p.order == 0) epilogue<GNK_F32, 2, 0>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw); else epilogue<GNK_F32, 2, 1>(p, acc, smem, wave, lane, mwave, nwave, lsc, mlw, nlw); }
         }
     }
 };
