@@ -73,7 +73,10 @@ PMC_TRAFFIC_BYTES = (2 * 49_398 + 32_768) * 1024   # rocprofv3 reports FETCH_SIZ
 
 
 def time_kernel(fn, iters=30, warm=5):
-    """Average launch duration in ms, HIP events on the current (= launch) stream."""
+    """Average launch duration in ms: ONE pair of HIP events on the current (= launch) stream around `iters` back-to-back launches, divided
+    by iters -- launch gaps between consecutive kernels included.  Second value: the median over per-launch event pairs, the method of
+    rounds 1-2; each pair of event records costs packets of its own (tools/probe_launch.hip: an empty kernel reads 6.0 us that way and
+    2.3-2.6 us back to back), so it reads ~3 us above the region average at any kernel size."""
     for _ in range(warm):
         fn()
     start = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
@@ -84,7 +87,13 @@ def time_kernel(fn, iters=30, warm=5):
         stop[i].record()
     torch.cuda.synchronize()
     ts = sorted(s.elapsed_time(e) for s, e in zip(start, stop))
-    return sum(ts) / len(ts), ts[len(ts) // 2]
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters, ts[len(ts) // 2]
 
 
 def time_kernel_graph(fn, per_graph=20, replays=6):
@@ -365,7 +374,7 @@ def main():
 
     if rank == 0:
         # dominant kernel for the roofline: scaled INT8 A@B.T (the training forward layout)
-        avg_ms, med_ms = time_kernel(lambda: gn_kernels.scaled_mm(*cases[("int8", "A@B.T")]), iters=50)
+        avg_ms, med_ms = time_kernel(lambda: gn_kernels.scaled_mm(*cases[("int8", "A@B.T")]), iters=100)
         achieved = 2 * S ** 3 / (avg_ms * 1e-3) * 1e-12
         out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_DENSE_8BIT_TOPS, "unit": "TFLOP/s",
                            "frac": round(achieved / PEAK_DENSE_8BIT_TOPS, 4), "traffic": PMC_TRAFFIC_BYTES,
@@ -373,7 +382,11 @@ def main():
                            "traffic_note": "memory-side bytes per launch measured in separate rocprofv3 --pmc passes over this kernel (profiles/r03c_pmc_int8_nt_4096_w4.txt; rounds 1-2, 8-wave kernels: r01e / r02d_pmc_int8_nt_4096.txt, within 0.2 %): "
                                            "FETCH_SIZE 50.6 MB x 2 (gfx950 correction) + WRITE_SIZE 33.6 MB (= the algorithmic 32 MiB of C); algorithmic bytes 67.1 MB -- "
                                            "the reads beyond 33.5 MB are per-XCD re-reads served by the Infinity Cache",
-                           "avg_launch_us": round(avg_ms * 1e3, 2), "median_launch_us": round(med_ms * 1e3, 2),
+                           "avg_launch_us": round(avg_ms * 1e3, 2), "per_launch_event_pair_median_us": round(med_ms * 1e3, 2),
+                           "frac_at_per_launch_event_pair_median": round(2 * S ** 3 / (med_ms * 1e-3) * 1e-12 / PEAK_DENSE_8BIT_TOPS, 4),
+                           "timing_note": "avg_launch_us = one HIP event pair around 100 back-to-back launches / 100 (launch gaps included); the per-launch event-pair "
+                                          "median (rounds 1-2's method, what rocprofv3's per-dispatch durations also track) carries ~3 us of event-record packets per "
+                                          "launch: an empty kernel reads 6.0 us that way, 2.3-2.6 us back to back (tools/probe_launch.hip, DESIGN 7)",
                            "algorithmic_ops_per_launch": 2 * S ** 3}
         bare = bare_mfma_rate()
         if bare and "i8_16x16x64_tops" in bare:

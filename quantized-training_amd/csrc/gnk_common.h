@@ -247,10 +247,16 @@ template <int DT> struct GnkAbsMax {
     }
 };
 
-// 16-byte store of a finished output tile row segment.  GNK_STORE_MODE (experiment, tools/store_mode_ab.sh): 0 plain write-back store;
-// 1 non-temporal; 2 sc1 (agent scope: written through the XCD's L2); 3 sc0 sc1 (system scope); 4 sc1 nt; 5 no store (timing ablation).
+// 16-byte store of a finished output tile row segment (the LDS-staged epilogues of the GEMM kernels).  Default: non-temporal.  Measured at
+// 4096^3 on the one-wave-per-SIMD kernel (tools/store_mode_ab.sh, profiles/r03k_*): plain write-back stores 55.8-57.3 us per launch,
+// nt / sc1 / sc0 sc1 / sc1 nt all 53.5-54.0, no store at all 55.4 on the box where plain was 57.6: with write-back stores the launch ends on
+// the write-back of the 32 MiB of dirty lines it left in the L2s; streamed out, that traffic overlaps the epilogue itself.
+// nt is the one flavour with a compiler builtin: the inline-asm forms (sc bits) hide the store from the compiler's hazard recognizer -- a
+// VALU write to the data registers in the two cycles behind a 16-byte store corrupts it (62 wrong outputs in the fp8 golden test) -- so
+// they carry their own s_nop and stay A/B builds.
+// GNK_STORE_MODE: 0 plain write-back; 1 non-temporal; 2 sc1; 3 sc0 sc1 (system scope); 4 sc1 nt; 5 no store (timing ablation, results wrong).
 #ifndef GNK_STORE_MODE
-#define GNK_STORE_MODE 0
+#define GNK_STORE_MODE 1
 #endif
 __device__ __forceinline__ void gnk_store16_out(void *ptr, const v4i &d) {
 #if GNK_STORE_MODE == 0
@@ -258,11 +264,11 @@ __device__ __forceinline__ void gnk_store16_out(void *ptr, const v4i &d) {
 #elif GNK_STORE_MODE == 1
     __builtin_nontemporal_store(d, (v4i *)ptr);
 #elif GNK_STORE_MODE == 2
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(ptr), "v"(d) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(ptr), "v"(d) : "memory");
 #elif GNK_STORE_MODE == 3
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(ptr), "v"(d) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(ptr), "v"(d) : "memory");
 #elif GNK_STORE_MODE == 4
-    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(ptr), "v"(d) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" : : "v"(ptr), "v"(d) : "memory");
 #else   // 5: timing ablation -- no store at all (results WRONG): what the output write costs a launch, tail included
     asm volatile("" : : "v"(ptr), "v"(d));
 #endif

@@ -467,10 +467,6 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams &p, typename AccT<
     const bool col_ok = nwave + 8 * sc8 < p.N;
     unsigned short *const cbase = (unsigned short *)p.C + (mwave + srow) * p.N + nwave + 8 * sc8;
     const int64_t cstep = 8 * p.N;
-#ifdef GNK_EPI_SC1
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(p.M * p.N * 2), 0x00020000);
-    const unsigned voff0 = (unsigned)(((mwave + srow) * p.N + nwave + 8 * sc8) * 2);
-#endif
     // row block i (16 rows) is complete after its NTL tiles: its two 8-row store groups go out at once, so global
     // stores overlap the conversion of the following row blocks (same wave wrote and reads its slice: in order)
 #pragma unroll
@@ -495,11 +491,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams &p, typename AccT<
         for (int it = 2 * i; it < 2 * i + 2; ++it) {
             const int row = it * 8 + srow;
             const v4i d = *(const GNK_LDS v4i *)(const GNK_LDS char *)(region + row * 128 + ((sc8 ^ (row & 7)) << 4));
-#ifdef GNK_EPI_SC1
-            if (col_ok && it * 8 < rows_left) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, d), rsrc, (int)(voff0 + it * (unsigned)(2 * cstep)), 0, 16);
-#else
-            if (col_ok && it * 8 < rows_left) *(v4i *)(cbase + it * cstep) = d;
-#endif
+            if (col_ok && it * 8 < rows_left) gnk_store16_out(cbase + it * cstep, d);
         }
     }
 }

@@ -227,14 +227,24 @@ class Gen:
                 for f in range(self.nf):
                     e(f"v_xor_b32 v{base + f}, {(16 if self.op == 'i8' else 32) * f}, {src}")
         # prologue: four stages of every operand in flight
-        for g in self.prologue_groups():
+        # the 256 accumulator clears go out between the LDS-DMA issues (each of which holds the wave's next vector-memory issue for
+        # ~60-100 cycles while the VALU is free), not behind them
+        groups = self.prologue_groups()
+        npieces = sum(len(g) for g in groups)
+        cleared = 0
+        k = 0
+        for g in groups:
             for pc in g:
                 self.emit_piece(pc)
+                k += 1
+                upto = 256 * k // npieces
+                for r in range(cleared, upto):
+                    e(f"v_accvgpr_write_b32 a{r}, 0")
+                cleared = upto
             for operand in ("a", "b"):
                 if any(pc[0] == operand for pc in g):
                     self.advance(operand)
-        for r in range(256):
-            e(f"v_accvgpr_write_b32 a{r}, 0")
+        assert cleared == 256
         e(f"s_waitcnt vmcnt({self.vm_prologue})")
         e("s_barrier")
         for r in self.frag_reads(0, 0):
