@@ -285,12 +285,10 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
         if (plan.splits > 1 && c.ws_bytes >= (int64_t)plan.splits * c.M * c.N * 4) { splits = plan.splits; first_steps = plan.first_steps; }
         // Round 3: the one-wave-per-SIMD kernel takes every 256 x 256 launch it can (K a multiple of 256; split-K chunks likewise).  Measured at
         // 4096^3 against the 8-phase kernel on one box (tools/cmp_variants.py): int8 A@B.T 57.4 vs 57.9 us, A@B 56.6 vs 59.8, A.T@B 56.8 vs 64.0;
-        // fp8 56.0 / 55.6 / 55.7 vs 55.8 / 57.6 / 61.2; at K = 8192 101.0-102.6 vs 103.7-117.5.
-        // Exception: both operands K-major (A@B.T) with more tiles than CUs -- the forward GEMMs of training (32768 x {2048, 5632} x 2048: 113-120 vs
-        // 119-129 us, 298 vs 313; x 2048 x 5632: 268 vs 291) stay on the 8-phase kernel: both K-major super-stages fall free in the same (odd)
-        // stage, where 16 LDS-DMA issues per wave do not hide behind 64 MFMAs.
-        const bool kk_many_tiles = la.kmajor && lb.kmajor && ((c.M + 255) / 256) * ((c.N + 255) / 256) > gnk_num_cus() && ok_128 && whole_steps;
-        if (variant == GNK_VARIANT_256 && allow_w4 && ok_w4 && !(kk_many_tiles && splits == 1)) {
+        // fp8 56.0 / 55.6 / 55.7 vs 55.8 / 57.6 / 61.2; at K = 8192 101.0-102.6 vs 103.7-117.5.  The forward GEMMs of training (A@B.T, more tiles
+        // than CUs: 32768 x {2048, 5632} x 2048, x 2048 x 5632) are level with the 8-phase kernel since the output stores became non-temporal
+        // (118-125 / 315-316 / 256 vs 120-124 / 325-329 / 261 us, profiles/r03p_*), so there is no exception for them.
+        if (variant == GNK_VARIANT_256 && allow_w4 && ok_w4) {
             if (splits == 1) {
                 variant = GNK_VARIANT_256_W4;
             } else if (first_steps > 0) {

@@ -403,6 +403,19 @@ template <class Cfg> struct EpiScales {
         static_assert(ORDER == 0 || ORDER == 1, "multiply order is a compile-time choice");
         return __fmul_rn(__fmul_rn(a, cs[j][r]), rs[i]);
     }
+    // Elements r, r + 1 of one lane's tile row at once: the two scale multiplies as v_pk_mul_f32 (each half rounded like v_mul_f32, so
+    // the bits do not change; the staged epilogues are VALU-issue bound with one or two waves per SIMD: 5.1 us of a 49 us 4096^3 launch).
+    template <int ORDER, class AccT_>
+    __device__ __forceinline__ v2f value2(const GemmParams &p, const AccT_ &acc, const v4f *accf, int i, int j, int r) const {
+        if constexpr (Cfg::EPI == EPI_TILE) return (v2f){(*accf)[r], (*accf)[r + 1]};
+        v2f a;
+        if constexpr (Cfg::OP == OP_I8) a = (v2f){(float)acc[r], (float)acc[r + 1]};
+        else a = (v2f){acc[r], acc[r + 1]};
+        if constexpr (Cfg::EPI == EPI_PLAIN) return a;
+        const v2f r2 = {rs[i], rs[i]}, c2 = {cs[j][r], cs[j][r + 1]};
+        if constexpr (ORDER == 0) return (a * r2) * c2;
+        return (a * c2) * r2;
+    }
 };
 
 // Final values of one lane -> memory.  For OUT == GNK_I32 the floats carry int32 bit patterns.
@@ -467,32 +480,44 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams &p, typename AccT<
     const bool col_ok = nwave + 8 * sc8 < p.N;
     unsigned short *const cbase = (unsigned short *)p.C + (mwave + srow) * p.N + nwave + 8 * sc8;
     const int64_t cstep = 8 * p.N;
-    // row block i (16 rows) is complete after its NTL tiles: its two 8-row store groups go out at once, so global
-    // stores overlap the conversion of the following row blocks (same wave wrote and reads its slice: in order)
+    // Row block i (16 rows) is complete after its NTL tiles.  Its two 16-byte read-backs are issued right behind its writes (same wave,
+    // same slice: LDS executes them in order), but its two global stores go out one row block LATER, behind the conversion of block i + 1:
+    // with one wave per SIMD nothing else hides the LDS round trip of every block (round 3; ~0.5 us per 128-row half before).
+    v4i d[2];
 #pragma unroll
     for (int i = 0; i < Cfg::MT; ++i) {
 #pragma unroll
         for (int j = 0; j < Cfg::NTL; ++j) {
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = sc.template value<ORDER>(p, acc[i][j], Cfg::EPI == EPI_TILE ? &accf[i][j] : nullptr, i, j, r);
+            const v2f v01 = sc.template value2<ORDER>(p, acc[i][j], Cfg::EPI == EPI_TILE ? &accf[i][j] : nullptr, i, j, 0);
+            const v2f v23 = sc.template value2<ORDER>(p, acc[i][j], Cfg::EPI == EPI_TILE ? &accf[i][j] : nullptr, i, j, 2);
             v2i o;
             if constexpr (OUT == GNK_BF16) {
-                o[0] = (int)gnk_pack2_bf16(v[0], v[1]);
-                o[1] = (int)gnk_pack2_bf16(v[2], v[3]);
+                o[0] = (int)gnk_pack2_bf16(v01[0], v01[1]);
+                o[1] = (int)gnk_pack2_bf16(v23[0], v23[1]);
             } else {
-                o[0] = (int)gnk_pack2_f16(v[0], v[1]);
-                o[1] = (int)gnk_pack2_f16(v[2], v[3]);
+                o[0] = (int)gnk_pack2_f16(v01[0], v01[1]);
+                o[1] = (int)gnk_pack2_f16(v23[0], v23[1]);
             }
             const int row = 16 * i + ml;
             *(GNK_LDS v2i *)(GNK_LDS char *)(region + row * 128 + (((2 * j + (g >> 1)) ^ (ml & 7)) << 4) + 8 * (g & 1)) = o;
         }
+        if (i > 0) {
 #pragma unroll
-        for (int it = 2 * i; it < 2 * i + 2; ++it) {
-            const int row = it * 8 + srow;
-            const v4i d = *(const GNK_LDS v4i *)(const GNK_LDS char *)(region + row * 128 + ((sc8 ^ (row & 7)) << 4));
-            if (col_ok && it * 8 < rows_left) gnk_store16_out(cbase + it * cstep, d);
+            for (int u = 0; u < 2; ++u) {
+                const int it = 2 * (i - 1) + u;
+                if (col_ok && it * 8 < rows_left) gnk_store16_out(cbase + it * cstep, d[u]);
+            }
         }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = (2 * i + u) * 8 + srow;
+            d[u] = *(const GNK_LDS v4i *)(const GNK_LDS char *)(region + row * 128 + ((sc8 ^ (row & 7)) << 4));
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int it = 2 * (Cfg::MT - 1) + u;
+        if (col_ok && it * 8 < rows_left) gnk_store16_out(cbase + it * cstep, d[u]);
     }
 }
 

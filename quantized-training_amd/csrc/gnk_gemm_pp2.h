@@ -223,6 +223,7 @@ template <class Cfg> struct PP2F8 {
         const bool col_ok = nwave + 8 * sc8 < p.N;
         unsigned short *const cbase = (unsigned short *)p.C + (mwave + srow) * p.N + nwave + 8 * sc8;
         const int64_t cstep = 8 * p.N;
+        v4i dq[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -250,13 +251,27 @@ template <class Cfg> struct PP2F8 {
                         store4<OUT, MODE == 1>(p.C, mwave + 32 * i + ml, nwave + 32 * j + 8 * g + 4 * h, p.M, p.N, v[0], v[1], v[2], v[3]);
                     }
                 }
-            if constexpr (MODE == 0) {   // rows 32 i .. 32 i + 31 are complete: store them while the next row block converts
+            if constexpr (MODE == 0) {   // rows 32 i .. 32 i + 31 are complete: read them back now, store them behind the NEXT row block's
+                                         // conversion (epilogue_lds: one wave per SIMD has nothing else to hide the LDS round trip with)
+                if (i > 0) {
 #pragma unroll
-                for (int it = 4 * i; it < 4 * i + 4; ++it) {
-                    const int row = it * 8 + srow;
-                    const v4i d = *(const GNK_LDS v4i *)(const GNK_LDS char *)(region + row * 128 + ((sc8 ^ (row & 7)) << 4));
-                    if (col_ok && it * 8 < rows_left) gnk_store16_out(cbase + it * cstep, d);
+                    for (int u = 0; u < 4; ++u) {
+                        const int it = 4 * (i - 1) + u;
+                        if (col_ok && it * 8 < rows_left) gnk_store16_out(cbase + it * cstep, dq[u]);
+                    }
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int row = (4 * i + u) * 8 + srow;
+                    dq[u] = *(const GNK_LDS v4i *)(const GNK_LDS char *)(region + row * 128 + ((sc8 ^ (row & 7)) << 4));
+                }
+            }
+        }
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int it = 12 + u;
+                if (col_ok && it * 8 < rows_left) gnk_store16_out(cbase + it * cstep, dq[u]);
             }
         }
     }

@@ -16,6 +16,20 @@
 
 namespace {
 
+// tuning knobs (A/B builds: tools/quant_ab.sh)
+#ifndef GNK_RC_PREFETCH_BELOW
+#define GNK_RC_PREFETCH_BELOW 12     // quant_rowwise_colmax_kernel prefetches the next row while NCH < this
+#endif
+#ifndef GNK_RC_CAP
+#define GNK_RC_CAP 2                 // its persistent grid: blocks (8 waves) per CU
+#endif
+#ifndef GNK_COLQ_WIDE
+#define GNK_COLQ_WIDE 1               // column-wise pass with a given absmax: the one-row-lane shape for wide matrices
+#endif
+#ifndef GNK_COLQ_PB
+#define GNK_COLQ_PB 128              // rows per block of the column-wise pass with a given absmax (large matrices)
+#endif
+
 template <int DT> struct ElemTraits;
 template <> struct ElemTraits<GNK_BF16> { static constexpr int VEC = 8; };
 template <> struct ElemTraits<GNK_F16>  { static constexpr int VEC = 8; };
@@ -218,7 +232,7 @@ quant_rowwise_colmax_kernel(const char *__restrict__ x, int8_t *__restrict__ q, 
     // The next row is prefetched while this one is processed, except for the widest rows: three row-sized register sets (row,
     // next row, column maxima: 144 registers at NCH = 12) spilled at the 128 registers that four waves per SIMD leave; there
     // the 16 waves of a CU with 12 loads in flight each hide the latency without a prefetch.
-    constexpr bool PREFETCH = NCH < 12;
+    constexpr bool PREFETCH = NCH < GNK_RC_PREFETCH_BELOW;
     v4i raw[NCH], nxt[PREFETCH ? NCH : 1];
     if constexpr (PREFETCH) {
 #pragma unroll
@@ -450,20 +464,24 @@ inline void col_partial_plan(int64_t P, bool wide, int64_t &rpb, int64_t &nparts
 }
 
 // PARTS: amax_ws holds `nparts` partial rows [nparts][Q] (col_absmax_partial_kernel) instead of one reduced row.
-template <int DT, bool SR, int COL_PB, bool NT, bool PARTS = false>
+// CLN: column-lanes per block (VEC columns each); 256 / CLN row-lanes.  32: 512-byte row segments, 8 row-lanes (round 1).  256: one
+// row-lane -- a block walks whole 4-KiB row spans (16-bit inputs) like the row-wise kernel does; for wide matrices the 512-byte segments
+// of 128 different rows per block ran at 4.0 TB/s where the row-wise pass reaches 5.6 (round 3, tools/quant_step_probe.py).
+template <int DT, bool SR, int COL_PB, bool NT, bool PARTS = false, int CLN = 32>
 __global__ void __launch_bounds__(256)
 col_quant_kernel(const char *__restrict__ x, int8_t *__restrict__ q, void *__restrict__ scale,
                  const unsigned *__restrict__ amax_ws, int64_t P, int64_t Q, int64_t ld_bytes,
                  int64_t ldq, float eps, unsigned long long seed, unsigned long long offset, int nparts) {
     constexpr int VEC = ElemTraits<DT>::VEC;
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int64_t col0 = ((int64_t)blockIdx.x * 32 + cl) * VEC;
+    constexpr int RL = 256 / CLN;
+    const int cl = threadIdx.x % CLN, rl = threadIdx.x / CLN;
+    const int64_t col0 = ((int64_t)blockIdx.x * CLN + cl) * VEC;
     const int64_t row0 = (int64_t)blockIdx.y * COL_PB;
-    __shared__ unsigned cm[PARTS ? 32 * VEC : 1];
+    __shared__ unsigned cm[PARTS ? CLN * VEC : 1];
     if constexpr (PARTS) {
         // the block's 32 * VEC columns, one per thread; the partial rows are L2 hits shared by every block of this column strip
-        for (int c = threadIdx.x; c < 32 * VEC; c += 256) {
-            const int64_t col = (int64_t)blockIdx.x * 32 * VEC + c;
+        for (int c = threadIdx.x; c < CLN * VEC; c += 256) {
+            const int64_t col = (int64_t)blockIdx.x * CLN * VEC + c;
             unsigned v = 0u;
             if (col < Q) {
                 for (int g0 = 0; g0 < nparts; g0 += 8) {
@@ -491,8 +509,8 @@ col_quant_kernel(const char *__restrict__ x, int8_t *__restrict__ q, void *__res
     // all of this thread's rows are loaded before the first is used: 16 x 16 B in flight per lane.  Row of slot i: interleaved
     // over the 8 row-lanes (i * 8 + rl), except under stochastic rounding, where a thread takes NIT CONSECUTIVE rows: logical
     // element indices of the (Q, P) view run along the rows, and four consecutive ones share a Philox block.
-    constexpr int NIT = COL_PB / 8;
-    auto row_of = [&](int i) -> int64_t { return SR ? row0 + rl * NIT + i : row0 + i * 8 + rl; };
+    constexpr int NIT = COL_PB / RL;
+    auto row_of = [&](int i) -> int64_t { return SR ? row0 + rl * NIT + i : row0 + i * RL + rl; };
     auto store_row = [&](int64_t row, const int (&qi)[VEC]) {
         if constexpr (VEC == 8) {
             v2i o = {(int)pack4_i8(qi[0], qi[1], qi[2], qi[3]), (int)pack4_i8(qi[4], qi[5], qi[6], qi[7])};
@@ -656,7 +674,7 @@ int launch_colwise(const void *x, int8_t *q, void *scale, int64_t P, int64_t Q, 
 }
 
 inline int64_t rowcol_blocks(int64_t R) {
-    const int64_t want = (R + 7) / 8, cap = (int64_t)gnk_num_cus() * 2;
+    const int64_t want = (R + 7) / 8, cap = (int64_t)gnk_num_cus() * GNK_RC_CAP;
     return want < cap ? want : cap;
 }
 
@@ -690,9 +708,14 @@ int launch_colwise_given(const void *x, int8_t *q, void *scale, int64_t P, int64
     const int64_t ld_bytes = ld * (16 / VEC);
     const int64_t gx = (Q + 32 * VEC - 1) / (32 * VEC);
     const dim3 block(256);
-    if (gx * ((P + 127) / 128) * 2 >= (int64_t)gnk_num_cus()) {
-        const dim3 grid((unsigned)gx, (unsigned)((P + 127) / 128));
-        hipLaunchKernelGGL((col_quant_kernel<DT, SR, 128, true>), grid, block, 0, st, (const char *)x, q, scale, amax, P, Q, ld_bytes, ldq, eps, seed, offset, 0);
+    // measured (tools/quant_step_probe.py, cold 32768-row tensors): 2048 columns 48.6 vs 50.2 us, 5632 columns (three blocks per row) 116.6 vs 115.3
+    if (GNK_COLQ_WIDE && Q >= 128 * VEC && Q <= 256 * VEC && ((P + 15) / 16) * ((Q + 256 * VEC - 1) / (256 * VEC)) * 2 >= (int64_t)gnk_num_cus()) {
+        // wide matrices: one row-lane, 256 column-lanes, 16 rows per block
+        const dim3 grid((unsigned)((Q + 256 * VEC - 1) / (256 * VEC)), (unsigned)((P + 15) / 16));
+        hipLaunchKernelGGL((col_quant_kernel<DT, SR, 16, true, false, 256>), grid, block, 0, st, (const char *)x, q, scale, amax, P, Q, ld_bytes, ldq, eps, seed, offset, 0);
+    } else if (gx * ((P + 127) / 128) * 2 >= (int64_t)gnk_num_cus()) {
+        const dim3 grid((unsigned)gx, (unsigned)((P + GNK_COLQ_PB - 1) / GNK_COLQ_PB));
+        hipLaunchKernelGGL((col_quant_kernel<DT, SR, GNK_COLQ_PB, true>), grid, block, 0, st, (const char *)x, q, scale, amax, P, Q, ld_bytes, ldq, eps, seed, offset, 0);
     } else {
         const dim3 grid((unsigned)gx, (unsigned)((P + 31) / 32));
         hipLaunchKernelGGL((col_quant_kernel<DT, SR, 32, false>), grid, block, 0, st, (const char *)x, q, scale, amax, P, Q, ld_bytes, ldq, eps, seed, offset, 0);
