@@ -478,6 +478,19 @@ col_quant_kernel(const char *__restrict__ x, int8_t *__restrict__ q, void *__res
     const int64_t col0 = ((int64_t)blockIdx.x * CLN + cl) * VEC;
     const int64_t row0 = (int64_t)blockIdx.y * COL_PB;
     __shared__ unsigned cm[PARTS ? CLN * VEC : 1];
+    // all of this thread's rows are loaded before the first is used: 16 x 16 B in flight per lane, and they are ISSUED before the absmax words
+    // are waited for (round 3: eight dword loads of the absmax and the divisor set-up sat in front of them, a dependent ~1.5 us at the head of
+    // every block).  Row of slot i: interleaved over the row-lanes (i * RL + rl), except under stochastic rounding, where a thread takes NIT
+    // CONSECUTIVE rows: logical element indices of the (Q, P) view run along the rows, and four consecutive ones share a Philox block.
+    constexpr int NIT = COL_PB / RL;
+    auto row_of = [&](int i) -> int64_t { return SR ? row0 + rl * NIT + i : row0 + i * RL + rl; };
+    v4i raw[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int64_t row = row_of(i);
+        raw[i] = (v4i){0, 0, 0, 0};
+        if (row < P && col0 < Q) raw[i] = *(const v4i *)(x + row * ld_bytes + col0 * (16 / VEC));
+    }
     if constexpr (PARTS) {
         // the block's 32 * VEC columns, one per thread; the partial rows are L2 hits shared by every block of this column strip
         for (int c = threadIdx.x; c < CLN * VEC; c += 256) {
@@ -497,20 +510,29 @@ col_quant_kernel(const char *__restrict__ x, int8_t *__restrict__ q, void *__res
         __syncthreads();
     }
     if (col0 >= Q) return;
+    unsigned am[VEC];
+    if constexpr (PARTS) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) am[j] = cm[cl * VEC + j];
+    } else if (((uintptr_t)amax_ws & 15) != 0) {   // a caller's absmax vector need only be 4-byte aligned (include/gnk.h)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) am[j] = amax_ws[col0 + j];
+    } else {                                   // col0 is a multiple of VEC: VEC / 4 wide loads
+#pragma unroll
+        for (int j4 = 0; j4 < VEC / 4; ++j4) {
+            const v4i w = *(const v4i *)(amax_ws + col0 + 4 * j4);
+            am[4 * j4] = (unsigned)w[0]; am[4 * j4 + 1] = (unsigned)w[1]; am[4 * j4 + 2] = (unsigned)w[2]; am[4 * j4 + 3] = (unsigned)w[3];
+        }
+    }
     GnkDivisor dv[VEC];
     bool fast = true;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-        const float s = __uint_as_float(PARTS ? cm[cl * VEC + j] : amax_ws[col0 + j]) / 127.0f;
+        const float s = __uint_as_float(am[j]) / 127.0f;
         dv[j].set(gnk_clamp_min_nan(s, eps));
         fast = fast && dv[j].ok();
         if (blockIdx.y == 0 && rl == 0) gnk_store_scalar_rt(scale, DT, col0 + j, s);
     }
-    // all of this thread's rows are loaded before the first is used: 16 x 16 B in flight per lane.  Row of slot i: interleaved
-    // over the 8 row-lanes (i * 8 + rl), except under stochastic rounding, where a thread takes NIT CONSECUTIVE rows: logical
-    // element indices of the (Q, P) view run along the rows, and four consecutive ones share a Philox block.
-    constexpr int NIT = COL_PB / RL;
-    auto row_of = [&](int i) -> int64_t { return SR ? row0 + rl * NIT + i : row0 + i * RL + rl; };
     auto store_row = [&](int64_t row, const int (&qi)[VEC]) {
         if constexpr (VEC == 8) {
             v2i o = {(int)pack4_i8(qi[0], qi[1], qi[2], qi[3]), (int)pack4_i8(qi[4], qi[5], qi[6], qi[7])};
@@ -520,13 +542,6 @@ col_quant_kernel(const char *__restrict__ x, int8_t *__restrict__ q, void *__res
             *(unsigned *)(q + row * ldq + col0) = pack4_i8(qi[0], qi[1], qi[2], qi[3]);
         }
     };
-    v4i raw[NIT];
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-        const int64_t row = row_of(i);
-        raw[i] = (v4i){0, 0, 0, 0};
-        if (row < P) raw[i] = *(const v4i *)(x + row * ld_bytes + col0 * (16 / VEC));
-    }
     if constexpr (SR) {
         const bool aligned = ((P | (int64_t)offset) & 3) == 0;      // every 4-row group then starts a Philox block
 #pragma unroll
