@@ -72,11 +72,41 @@ def make_inputs(S, dev):
 PMC_TRAFFIC_BYTES = (2 * 49_398 + 32_768) * 1024   # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; see roofline.traffic_note (profiles/r03c_pmc_int8_nt_4096_w4.txt)
 
 
+PREWARM_MS = 120.0   # tools/ramp_probe.py: after an idle period the six-GEMM step takes ~80 steps (~30 ms) to reach its steady time
+                     # (first 20 steps 375-397 us, steps 20-40 355, 40-80 340, then 332 us: the chip's clocks ramp with load)
+
+
+def prewarm(fn, ms=PREWARM_MS):
+    """Run `fn` for `ms` milliseconds of GPU time, untimed: brings the clocks to the state they hold under sustained load, so that what
+    follows measures steady-state throughput and not the ramp after an idle period.  Returns (calls, ms)."""
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    calls = 0
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(8):
+            fn()
+        calls += 8
+        torch.cuda.synchronize()
+    return calls, (time.perf_counter() - t0) * 1e3
+
+
+_last_gpu_work = [0.0]
+
+
+def prewarm_if_idle(fn, idle_s=0.05, ms=40.0):
+    """The detail tables time many short regions with host work (allocation, the CPU baseline, sub-processes) between them: pre-warm again
+    whenever the GPU has been idle for more than `idle_s`."""
+    now = time.perf_counter()
+    if now - _last_gpu_work[0] > idle_s:
+        prewarm(fn, ms)
+
+
 def time_kernel(fn, iters=30, warm=5):
     """Average launch duration in ms: ONE pair of HIP events on the current (= launch) stream around `iters` back-to-back launches, divided
     by iters -- launch gaps between consecutive kernels included.  Second value: the median over per-launch event pairs, the method of
     rounds 1-2; each pair of event records costs packets of its own (tools/probe_launch.hip: an empty kernel reads 6.0 us that way and
     2.3-2.6 us back to back), so it reads ~3 us above the region average at any kernel size."""
+    prewarm_if_idle(fn)
     for _ in range(warm):
         fn()
     start = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
@@ -93,6 +123,7 @@ def time_kernel(fn, iters=30, warm=5):
         fn()
     b.record()
     torch.cuda.synchronize()
+    _last_gpu_work[0] = time.perf_counter()
     return a.elapsed_time(b) / iters, ts[len(ts) // 2]
 
 
@@ -112,7 +143,7 @@ def time_kernel_graph(fn, per_graph=20, replays=6):
                 fn()
     torch.cuda.current_stream().wait_stream(side)
     g.replay()
-    torch.cuda.synchronize()
+    prewarm(g.replay, 40.0)        # capture is host work: the GPU idled meanwhile
     ts = []
     for _ in range(replays):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -339,6 +370,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # untimed, before the W warm-up steps: steady clocks (see prewarm); every rank does the same
+    prewarm_calls, prewarm_ms = prewarm(step)
     for _ in range(args.warmup):
         step()
     sync()
@@ -368,6 +401,9 @@ def main():
         "vs_baseline": None,
         "dtype": "int8+fp8_e4m3 (int32 / fp32 accumulate, bf16 out)",
         "data": "synthetic",
+        "prewarm": {"steps": prewarm_calls, "ms": round(prewarm_ms, 1),
+                    "why": "untimed, before the W warm-up steps: after an idle period the chip needs ~30 ms of load to reach the clocks it then holds "
+                           "(tools/ramp_probe.py: step 375-397 us for the first 20 steps, 332 us from step 80 on); the timed region is steady state"},
         "config": {"workload": "configs[1]: scaled INT8 + scaled FP8 mm, M=N=K=4096, layouts A@B.T / A@B / A.T@B, 6 GEMMs per step",
                    "parallelism": f"replicas x{world}" if world > 1 else "single GPU"},
     }
