@@ -6,5 +6,5 @@ repo=$PWD
 out=$repo/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out -o bench --output-format csv -- python3 $repo/bench.py --steps 20 --warmup 5 --no-cpu --no-train --no-detail > $out/bench_under_rocprof.json 2> $out/rocprof.log
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out -o bench --output-format csv -- python3 $repo/bench.py --no-cpu --no-train --no-detail > $out/bench_under_rocprof.json 2> $out/rocprof.log
 find $out -name "*.csv"
