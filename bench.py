@@ -335,8 +335,8 @@ def bare_mfma_rate():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-detail", action="store_true", help="skip the untimed per-kernel sweep")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--no-train", action="store_true", help="skip the untimed Llama training tok/s runs (detail_train)")
