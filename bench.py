@@ -69,7 +69,8 @@ def make_inputs(S, dev):
     return cases
 
 
-PMC_TRAFFIC_BYTES = (2 * 49_398 + 32_768) * 1024   # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; see roofline.traffic_note (profiles/r03c_pmc_int8_nt_4096_w4.txt)
+PMC_TRAFFIC_BYTES = (2 * 49_383 + 32_770) * 1024   # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; see roofline.traffic_note (profiles/r03x_pmc_int8_nt_4096_w4.txt:
+                                                    # the round's final kernel; r03c, its first build, read 49,398 / 32,768)
 
 
 PREWARM_MS = 120.0   # tools/ramp_probe.py: after an idle period the six-GEMM step takes ~80 steps (~30 ms) to reach its steady time
@@ -415,7 +416,7 @@ def main():
         out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_DENSE_8BIT_TOPS, "unit": "TFLOP/s",
                            "frac": round(achieved / PEAK_DENSE_8BIT_TOPS, 4), "traffic": PMC_TRAFFIC_BYTES,
                            "kernel": "gemm_w4_kernel<256x256 tile, 4 waves (one per SIMD, 128x128 wave tiles), hand-scheduled asm loop, int8 v_mfma_i32_16x16x64_i8, A K-major, B K-major, row/col epilogue>",
-                           "traffic_note": "memory-side bytes per launch measured in separate rocprofv3 --pmc passes over this kernel (profiles/r03c_pmc_int8_nt_4096_w4.txt; rounds 1-2, 8-wave kernels: r01e / r02d_pmc_int8_nt_4096.txt, within 0.2 %): "
+                           "traffic_note": "memory-side bytes per launch measured in separate rocprofv3 --pmc passes over this kernel (profiles/r03x_pmc_int8_nt_4096_w4.txt; rounds 1-2, 8-wave kernels: r01e / r02d_pmc_int8_nt_4096.txt, within 0.2 %): "
                                            "FETCH_SIZE 50.6 MB x 2 (gfx950 correction) + WRITE_SIZE 33.6 MB (= the algorithmic 32 MiB of C); algorithmic bytes 67.1 MB -- "
                                            "the reads beyond 33.5 MB are per-XCD re-reads served by the Infinity Cache",
                            "avg_launch_us": round(avg_ms * 1e3, 2), "per_launch_event_pair_median_us": round(med_ms * 1e3, 2),
