@@ -31,6 +31,10 @@ if blk:
     rs = torch.randn(S if blk == 128 else S // blk, K // blk, device="cuda").div(128).bfloat16()
     cs = torch.randn(K // blk, S // blk, device="cuda").div(128).bfloat16()
 _cabi.load().gnk_set_gemm_variant(variant)
+import os
+if os.environ.get("GNK_TILE_RESCALE"):      # exact | fused | auto (gn_kernels.mm.set_tile_rescale)
+    from gn_kernels import mm
+    mm.set_tile_rescale(os.environ["GNK_TILE_RESCALE"])
 for _ in range(iters):
     gn_kernels.scaled_mm(A, B, rs, cs)
 torch.cuda.synchronize()
