@@ -263,11 +263,12 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
                              lb.ld * 256 < (1LL << 31) && ((c.M + 127) / 128) * ((c.N + 127) / 128) < (1LL << 31);
     // 4-stage 256^2 kernel: 64-k stages, no tile-scaled epilogue; the two-buffer kernels step 128 k
     const bool ok_pp2 = fast_layout && c.K >= 64 && c.K % 64 == 0 && c.epi != EPI_TILE;
-    // tile-scaled fast path: scale blocks of 64 or 32 k (2 or 4 per 128-k step) or of a multiple of 128 k, and scale offsets that fit 32-bit indices
+    // tile-scaled fast path: scale blocks of 64 or 32 k (2 or 4 per 128-k step) or of a multiple of 128 k, and scale offsets that fit 32-bit indices;
+    // QN % 4 != 0 (per-column scales) on the 128-k instances only (GemmCfg::PERCOL)
     bool tile_ok = true;
     if (c.epi == EPI_TILE) {
         const int64_t amax = ((c.M - 1) / c.QM) * c.ssam + (c.K / c.QK) * c.ssak, bmax = (c.K / c.QK) * c.ssbk + ((c.N - 1) / c.QN) * c.ssbn;
-        tile_ok = (c.QK % GNK_BK == 0 || c.QK == 64 || c.QK == 32) && c.QK / GNK_BK < (1 << 20) && c.K % c.QK == 0 && c.QN % 4 == 0 && c.N % 4 == 0 && c.ssam >= 0 && c.ssak >= 0 && c.ssbk >= 0 && c.ssbn >= 0 && amax < (1LL << 31) && bmax < (1LL << 31);
+        tile_ok = (c.QK % GNK_BK == 0 || c.QK == 64 || c.QK == 32) && c.QK / GNK_BK < (1 << 20) && c.K % c.QK == 0 && (c.QN % 4 == 0 || c.QK == GNK_BK) && c.N % 4 == 0 && c.ssam >= 0 && c.ssak >= 0 && c.ssbk >= 0 && c.ssbn >= 0 && amax < (1LL << 31) && bmax < (1LL << 31);
     }
     // the 128 x 128 kernel masks a K tail itself (any K; plain and row/col epilogues); the tile-scaled epilogue needs whole 128-k steps
     const bool ok_128 = fast_layout && c.K >= 1 && (c.K % GNK_BK == 0 || c.epi != EPI_TILE) && tile_ok;

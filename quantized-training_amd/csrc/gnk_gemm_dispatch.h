@@ -54,8 +54,12 @@ GNK_DECLARE_LAUNCHER(gnk_launch_f8_11_v1);
         switch (epi) {                                                                                      \
         case EPI_PLAIN: return gnk_gemm::launch<GemmCfg<BM, BN, WM, WN, AK, BK, OP, FA, FB, EPI_PLAIN>>(p, st);   \
         case EPI_ROWCOL: return gnk_gemm::launch<GemmCfg<BM, BN, WM, WN, AK, BK, OP, FA, FB, EPI_ROWCOL>>(p, st); \
-        default: return p.fused_rescale ? gnk_gemm::launch<GemmCfg<TBM, TBN, TWM, TWN, AK, BK, OP, FA, FB, EPI_TILE, GNK_BK, true>>(p, st)   \
-                                        : gnk_gemm::launch<GemmCfg<TBM, TBN, TWM, TWN, AK, BK, OP, FA, FB, EPI_TILE>>(p, st);            \
+        default:                                                                                            \
+            if (p.QN % 4 != 0)   /* per-column B scales (GemmCfg::PERCOL) */                                    \
+                return p.fused_rescale ? gnk_gemm::launch<GemmCfg<TBM, TBN, TWM, TWN, AK, BK, OP, FA, FB, EPI_TILE, GNK_BK, true, true>>(p, st)   \
+                                       : gnk_gemm::launch<GemmCfg<TBM, TBN, TWM, TWN, AK, BK, OP, FA, FB, EPI_TILE, GNK_BK, false, true>>(p, st); \
+            return p.fused_rescale ? gnk_gemm::launch<GemmCfg<TBM, TBN, TWM, TWN, AK, BK, OP, FA, FB, EPI_TILE, GNK_BK, true>>(p, st)   \
+                                   : gnk_gemm::launch<GemmCfg<TBM, TBN, TWM, TWN, AK, BK, OP, FA, FB, EPI_TILE>>(p, st);            \
         }                                                                                                   \
     }                                                                                                       \
     int NAME(bool a_kmajor, bool b_kmajor, int epi, const GemmParams &p, hipStream_t st) {                  \

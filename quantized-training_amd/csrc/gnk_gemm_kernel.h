@@ -52,9 +52,13 @@ struct GemmParams {
 // 256 stands for ANY multiple of 128 above 128: GemmParams::kgroup K-steps per block, a run-time number)
 // FUSED_: tile-scaled rescale as one fma per element with s = sA * sB (GemmParams::fused_rescale; its own instances: as a run-time branch
 // beside the three-rounding form the 256-register kernels spilled 14-20 registers)
-template <int BM_, int BN_, int WM_, int WN_, bool AK_, bool BK_, int OP_, int FA_, int FB_, int EPI_, int KB_ = GNK_BK, bool FUSED_ = false>
+// PERCOL_: tile-scaled with a scale block width QN that is NOT a multiple of 4 (per-column scales, QN = 1, 2, 3 ...): a lane's four consecutive
+// columns may sit in different blocks, so the B-side scales go through the LDS panel expanded per COLUMN and every element takes its own
+// (128-k block instances only; before round 3 these shapes fell to the generic kernel, 44-49 TOP/s)
+template <int BM_, int BN_, int WM_, int WN_, bool AK_, bool BK_, int OP_, int FA_, int FB_, int EPI_, int KB_ = GNK_BK, bool FUSED_ = false, bool PERCOL_ = false>
 struct GemmCfg {
-    static constexpr bool FUSED = FUSED_;
+    static constexpr bool FUSED = FUSED_, PERCOL = PERCOL_;
+    static_assert(!PERCOL_ || (EPI_ == 2 && KB_ == GNK_BK), "per-column B scales: tile-scaled epilogue with 128-k blocks");
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, KB = KB_;
     static_assert(KB_ == 128 || ((KB_ == 64 || KB_ == 32 || KB_ == 256) && EPI_ == 2), "scale blocks other than 128 k exist for the tile-scaled epilogue only");
     static constexpr bool A_KMAJOR = AK_, B_KMAJOR = BK_;
@@ -699,7 +703,7 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
     constexpr int NB = MULTI ? 1 : GNK_BK / Cfg::KB, PS = TS_STEPS / NB;    // PS: K-steps per panel
     // NB > 1: the B-side scales go through a second panel ([scale step][BN columns]) too -- NB x NTL per-lane values for this step
     // and as many in flight for the next one spilled registers.
-    constexpr bool PANEL_B = NB > 1;
+    constexpr bool PANEL_B = NB > 1 || Cfg::PERCOL;
     constexpr int TS_PEB = PANEL_B ? Cfg::BN * TS_STEPS / Cfg::NT : 1;
     const int nk = (int)((p.K + GNK_BK - 1) / GNK_BK);          // the last step may be partial (plain / row-col epilogues; host-checked)
     const int ktail = (int)(p.K % GNK_BK);                        // k elements of that partial step (0: none)
@@ -843,12 +847,16 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
                 }
                 // this block's scales from the panel(s) (fp32, [scale step][row] / [scale step][column])
                 float sav[MT], sbv[NTL];
+                v4f sbq[Cfg::PERCOL ? NTL : 1];     // PERCOL: one scale per column of the lane's quad
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
                     sav[i] = *(const GNK_LDS float *)(const GNK_LDS char *)((const char *)panel + ((tsi * NB + b) * Cfg::BM + wm * Cfg::WTM + 16 * i + (lane & 15)) * 4);
 #pragma unroll
                 for (int j = 0; j < NTL; ++j) {
-                    if constexpr (PANEL_B)
+                    if constexpr (Cfg::PERCOL) {
+                        sbq[j] = *(const GNK_LDS v4f *)(const GNK_LDS char *)((const char *)panel_b + ((tsi * NB + b) * Cfg::BN + wn * Cfg::WTN + 16 * j + 4 * (lane >> 4)) * 4);
+                        sbv[j] = sbq[j][0];
+                    } else if constexpr (PANEL_B)
                         sbv[j] = *(const GNK_LDS float *)(const GNK_LDS char *)((const char *)panel_b + ((tsi * NB + b) * Cfg::BN + wn * Cfg::WTN + 16 * j + 4 * (lane >> 4)) * 4);
                     else sbv[j] = sbv1[j];
                 }
@@ -868,7 +876,8 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
                                 float part;
                                 if constexpr (Cfg::OP == OP_I8) part = (float)acc[i][j][r];
                                 else part = acc[i][j][r];
-                                accf[i][j][r] = __builtin_fmaf(part, s, accf[i][j][r]);
+                                if constexpr (Cfg::PERCOL) accf[i][j][r] = __builtin_fmaf(part, __fmul_rn(sav[i], sbq[j][r]), accf[i][j][r]);
+                                else accf[i][j][r] = __builtin_fmaf(part, s, accf[i][j][r]);
                             }
                         }
                 } else {
@@ -883,7 +892,8 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
                                 if constexpr (Cfg::OP == OP_I8) part = (float)acc[i][j][r];
                                 else part = acc[i][j][r];
                                 float tmp = __fmul_rn(part, sav[i]);
-                                tmp = __fmul_rn(tmp, sbv[j]);
+                                if constexpr (Cfg::PERCOL) tmp = __fmul_rn(tmp, sbq[j][r]);
+                                else tmp = __fmul_rn(tmp, sbv[j]);
                                 accf[i][j][r] = __fadd_rn(accf[i][j][r], tmp);
                             }
                         }
@@ -903,7 +913,7 @@ __global__ void __launch_bounds__(Cfg::NT) __attribute__((amdgpu_waves_per_eu(Cf
 
 template <class Cfg> int launch(const GemmParams &p0, hipStream_t st) {
     constexpr int LDS_TOTAL = Cfg::LDS_BYTES + ScalePrefetch<Cfg::BM, Cfg::BN, Cfg::NT, Cfg::EPI>::BYTES + (Cfg::EPI == EPI_TILE ? Cfg::BM * 8 * 4 : 0) +
-                              (Cfg::EPI == EPI_TILE && Cfg::KB < GNK_BK ? Cfg::BN * 8 * 4 : 0);   // tile-scaled: A-side scale panel (+ B-side panel for 64 / 32-k blocks)
+                              (Cfg::EPI == EPI_TILE && (Cfg::KB < GNK_BK || Cfg::PERCOL) ? Cfg::BN * 8 * 4 : 0);   // tile-scaled: A-side scale panel (+ B-side panel for 64 / 32-k blocks and per-column scales)
     GemmParams p = p0;
     p.grid_m = (int)((p.M + Cfg::BM - 1) / Cfg::BM);
     p.grid_n = (int)((p.N + Cfg::BN - 1) / Cfg::BN);

@@ -189,6 +189,41 @@ def test_tile_scaled_int8_vs_oracle(blocks):
     assert bits_equal(got, oracle.scaled_mm(A, B, sA, sB))
 
 
+@pytest.mark.parametrize("qmn", [(1, 1), (128, 2), (1, 3), (4, 6)])
+@pytest.mark.parametrize("layout", list(LAYOUTS))
+def test_tile_scaled_per_column_scale_blocks(qmn, layout):
+    """Scale blocks whose width QN is not a multiple of 4 (per-column scales and the like; the reference takes any block size its shapes
+    give, triton_mm.py:419,434-437): 128-k blocks run on MFMA-kernel instances that read one B-side scale per COLUMN from the LDS panel
+    (GemmCfg::PERCOL).  int8 with fp32 scales bit for bit against the oracle (exact rescale), bf16 scales in the default fused form at the
+    reference's tolerance, fp8 at the stated fp8 tolerance; ragged M / N edges, K over several scale panels."""
+    QM, QN = qmn
+    QK = 128
+    M, N, K = 384 if QM == 128 else 400, 528, 128 * 11      # multiples of 16 (M/N-major operands), ragged against the 128 x 128 tile
+    assert M % QM == 0 and N % QN == 0 and N % 4 == 0 and QN % 4 != 0
+    g = torch.Generator().manual_seed(QM * 131 + QN * 17 + len(layout))
+    acm, bcm = LAYOUTS[layout]
+    A = to_layout(torch.randint(-128, 128, (M, K), dtype=torch.int8, generator=g), acm)
+    B = to_layout(torch.randint(-128, 128, (K, N), dtype=torch.int8, generator=g), bcm)
+    sA = torch.randn(M // QM, K // QK, generator=g).div(128)
+    sB = torch.randn(K // QK, N // QN, generator=g).div(128)
+    Ad, Bd = dev_layout(A, acm), dev_layout(B, bcm)
+    L = _cabi.load()
+    L.gnk_set_gemm_variant(VARIANTS["tile128"])            # a forced fast variant errors out instead of falling back to the generic kernel
+    try:
+        got = gn_kernels.scaled_mm(Ad, Bd, sA.to(DEV), sB.to(DEV))
+        assert bits_equal(got, oracle.scaled_mm(A, B, sA, sB))
+        want32 = oracle.scaled_mm(A, B, sA.bfloat16().float(), sB.bfloat16().float())
+        assert_tile_int8_close(gn_kernels.scaled_mm(Ad, Bd, sA.bfloat16().to(DEV), sB.bfloat16().to(DEV)), want32)
+        with tile_rescale("exact"):
+            assert bits_equal(gn_kernels.scaled_mm(Ad, Bd, sA.bfloat16().to(DEV), sB.bfloat16().to(DEV)), want32.bfloat16())
+        A8 = to_layout((torch.randn(M, K, generator=g) * 0.5).to(torch.float8_e4m3fn), acm)
+        B8 = to_layout((torch.randn(K, N, generator=g) * 0.5).to(torch.float8_e4m3fn), bcm)
+        got8 = gn_kernels.scaled_mm(dev_layout(A8, acm), dev_layout(B8, bcm), sA.to(DEV), sB.to(DEV))
+        assert_fp8_close(got8, oracle.scaled_mm(A8, B8, sA, sB), fp8_mag(A8, B8, sA, sB))
+    finally:
+        L.gnk_set_gemm_variant(-1)
+
+
 @pytest.mark.parametrize("blocks", [(32, 32, 32), (64, 64, 64), (1, 128, 32), (32, 4, 64), (128, 128, 256), (1, 64, 640), (32, 32, 1280)])
 @pytest.mark.parametrize("layout", list(LAYOUTS))
 def test_tile_scaled_small_k_blocks_int8_bit_exact(blocks, layout):
