@@ -119,6 +119,7 @@ gnk_gemm_launcher pick_launcher(int op, int fa, int fb, int variant) {
                : variant == GNK_VARIANT_256_SIMPLE ? gnk_launch_i8_v3
                : variant == GNK_VARIANT_256_PP8 ? gnk_launch_i8_v4
                : variant == GNK_VARIANT_256_W4 ? gnk_launch_i8_v5
+               : variant == GNK_VARIANT_64X128 ? gnk_launch_i8_v6
                                                 : gnk_launch_i8_v1;
     if (variant == GNK_VARIANT_256_W4) {
         static const gnk_gemm_launcher f8w4[2][2] = {{gnk_launch_f8_00_v5, gnk_launch_f8_01_v5}, {gnk_launch_f8_10_v5, gnk_launch_f8_11_v5}};
@@ -276,6 +277,9 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
     if ((variant == GNK_VARIANT_256_SIMPLE && op != OP_I8) || ((variant == GNK_VARIANT_256_SIMPLE || variant == GNK_VARIANT_256_PP8 || variant == GNK_VARIANT_256_W4) && c.epi == EPI_TILE)) variant = GNK_VARIANT_256;
     const bool ok_w4 = ok_pp2 && c.K % 256 == 0;   // one-wave-per-SIMD kernel: four 64-k stages per loop iteration
     if (variant == GNK_VARIANT_256_W4 && !ok_w4) variant = GNK_VARIANT_256;
+    // 64 x 128 tile: int8, plain / row-col epilogue (any K: it masks a K tail like the 128 x 128 kernel)
+    const bool ok_64 = ok_128 && op == OP_I8 && c.epi != EPI_TILE;
+    if (variant == GNK_VARIANT_64X128 && !ok_64) variant = GNK_VARIANT_128;
     if (variant == GNK_VARIANT_256 && c.epi == EPI_TILE) variant = GNK_VARIANT_128;
     int splits = 1, first_steps = 0;
     if (variant < 0 || variant > GNK_VARIANT_LAST) {
@@ -306,8 +310,16 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
         // 32768 x 2048 x 5632: 315 vs 337 us; x 8192: 446 vs 468) stays on the 4-stage kernel; at K = 2048 the 8-phase kernel wins there too.
         const bool narrow_long_nn = !lb.kmajor && c.N <= 2048 && c.K >= 4096 && c.M >= 4 * c.N;
         if (variant == GNK_VARIANT_256 && splits == 1 && la.kmajor && ok_128 && whole_steps && !narrow_long_nn) variant = GNK_VARIANT_256_PP8;
+        // Round 3: few 128 x 128 tiles (at most one workgroup per CU, where a 128-k step takes 1.0 us instead of the 0.55 us two co-resident workgroups
+        // reach): 64 x 128 tiles double the workgroups.  Measured (tools/mid_ab.py, one box): 1024^3 A@B.T 9.0 -> 7.5 us, A.T@B 10.1 -> 8.7;
+        // 2048^3 A@B.T 15.2 -> 13.9 (A@B 16.9 -> 16.4, A.T@B 16.5 -> 17.2: not taken); from 512 tiles up the 128 x 128 tile wins (8192 x 1024 x 1024:
+        // 11.6 vs 14.5 us).
+        if (variant == GNK_VARIANT_128 && splits == 1 && ok_64 && g_forced_variant != GNK_VARIANT_AUTO_NO_64) {
+            const int64_t tiles128 = ((c.M + 127) / 128) * ((c.N + 127) / 128), cus = gnk_num_cus();
+            if (tiles128 * 2 <= cus || (tiles128 <= cus && la.kmajor && lb.kmajor)) variant = GNK_VARIANT_64X128;
+        }
     } else if (variant != GNK_VARIANT_GENERIC &&
-               !((variant == GNK_VARIANT_256 || variant == GNK_VARIANT_256_W4) ? ok_pp2 : variant == GNK_VARIANT_128 ? ok_128 : (ok_128 && whole_steps))) {
+               !((variant == GNK_VARIANT_256 || variant == GNK_VARIANT_256_W4) ? ok_pp2 : (variant == GNK_VARIANT_128 || variant == GNK_VARIANT_64X128) ? ok_128 : (ok_128 && whole_steps))) {
         return gnk_fail(GNK_ERR_UNSUPPORTED, "%s: forced fast variant %d cannot take these strides / sizes", name, variant);
     }
 

@@ -333,11 +333,11 @@ __device__ __forceinline__ void store4(void *C, int64_t m, int64_t n, int64_t M,
 // per launch: 2.5 % of a 4096^3 product, 6 % of the K = 1024 products of a Llama-470m step).
 template <int BM, int BN, int NT, int EPI> struct ScalePrefetch {
     static constexpr int BYTES = EPI == EPI_ROWCOL ? (BM + BN) * 4 : 0;
-    static_assert(BM + BN == NT, "one scale per thread");
+    static_assert(BM + BN <= NT, "at most one scale per thread");
     unsigned raw;
     __device__ __forceinline__ void issue(const GemmParams &p, int64_t m0, int64_t n0) {
         if constexpr (EPI == EPI_ROWCOL) {
-            const int t = threadIdx.x;
+            const int t = (int)threadIdx.x < BM + BN ? (int)threadIdx.x : BM + BN - 1;   // 64 x 128 tiles: the last 64 threads repeat a load
             const bool row = t < BM;
             int64_t idx = row ? m0 + t : n0 + (t - BM);
             const int64_t last = row ? p.M - 1 : p.N - 1;
@@ -350,7 +350,7 @@ template <int BM, int BN, int NT, int EPI> struct ScalePrefetch {
     __device__ __forceinline__ void park(const GemmParams &p, char *lds) const {
         if constexpr (EPI == EPI_ROWCOL) {
             const float v = gnk_raw_to_f32_rt(raw, p.scale_dtype);
-            *(GNK_LDS float *)(GNK_LDS char *)(lds + 4 * threadIdx.x) = v;
+            if ((int)threadIdx.x < BM + BN) *(GNK_LDS float *)(GNK_LDS char *)(lds + 4 * threadIdx.x) = v;
         }
     }
 };

@@ -28,8 +28,11 @@ constexpr int GNK_BK = 128;   // bytes (= elements) of K per staged tile
 GNK_HD int gnk_kmaj_offset(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 
 template <int L> GNK_HD int gnk_mnmaj_swz(int k) {
-    static_assert(L == 128 || L == 256, "MN-major tiles are 128 or 256 bytes wide");
+    static_assert(L == 64 || L == 128 || L == 256, "MN-major tiles are 64, 128 or 256 bytes wide");
     if (L == 256) return ((k & 7) << 1) | ((k >> 4) & 1);
+    // 64-byte k-rows (64-row tiles, round 3): four k-rows share a 256-byte bank window, and a half-wave of a ds_read_b64_tr_b8 touches
+    // k = q, q + 4, 16 + q, 20 + q for each of them -- bits 2 and 4 of k pick four different 16-byte slots
+    if (L == 64) return ((k >> 2) & 1) | (((k >> 4) & 1) << 1);
     return (((k >> 1) & 3) << 1) | ((k >> 4) & 1);
 }
 template <int L> GNK_HD int gnk_mnmaj_offset(int k, int c) { return k * L + ((c ^ gnk_mnmaj_swz<L>(k)) << 4); }

@@ -216,6 +216,7 @@ int main() {
     sim_mn64_frag16();
     sim_kmajor<128>();
     sim_kmajor<256>();
+    sim_mnmajor<64>();
     sim_mnmajor<128>();
     sim_mnmajor<256>();
     if (fails) { printf("FAILED: %d checks\n", fails); return 1; }

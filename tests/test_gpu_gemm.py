@@ -12,7 +12,7 @@ from tests._util import FLOAT_DTYPES, FP8_DTYPES, LAYOUTS, bits_equal, load, t_f
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-VARIANTS = {"auto": -1, "tile256": 0, "tile128": 1, "generic": 2, "tile256simple": 3, "tile256pp8": 4, "tile256w4": 5}
+VARIANTS = {"auto": -1, "tile256": 0, "tile128": 1, "generic": 2, "tile256simple": 3, "tile256pp8": 4, "tile256w4": 5, "tile64x128": 6}
 
 
 @pytest.fixture(params=list(VARIANTS))
