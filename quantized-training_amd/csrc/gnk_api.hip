@@ -277,8 +277,8 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
     if ((variant == GNK_VARIANT_256_SIMPLE && op != OP_I8) || ((variant == GNK_VARIANT_256_SIMPLE || variant == GNK_VARIANT_256_PP8 || variant == GNK_VARIANT_256_W4) && c.epi == EPI_TILE)) variant = GNK_VARIANT_256;
     const bool ok_w4 = ok_pp2 && c.K % 256 == 0;   // one-wave-per-SIMD kernel: four 64-k stages per loop iteration
     if (variant == GNK_VARIANT_256_W4 && !ok_w4) variant = GNK_VARIANT_256;
-    // 64 x 128 tile: int8, plain / row-col epilogue (any K: it masks a K tail like the 128 x 128 kernel)
-    const bool ok_64 = ok_128 && op == OP_I8 && c.epi != EPI_TILE;
+    // 64 x 128 tile: plain / row-col epilogue (any K: it masks a K tail like the 128 x 128 kernel)
+    const bool ok_64 = ok_128 && c.epi != EPI_TILE;
     if (variant == GNK_VARIANT_64X128 && !ok_64) variant = GNK_VARIANT_128;
     if (variant == GNK_VARIANT_256 && c.epi == EPI_TILE) variant = GNK_VARIANT_128;
     int splits = 1, first_steps = 0;
@@ -375,6 +375,7 @@ int run_gemm(const char *name, const GemmCall &c, hipStream_t st) {
         if (fa == F8_E4M3) return fb == F8_E4M3 ? gnk_launch_tkb_f8_00((int)c.QK, la.kmajor, lb.kmajor, p, st) : gnk_launch_tkb_f8_01((int)c.QK, la.kmajor, lb.kmajor, p, st);
         return fb == F8_E4M3 ? gnk_launch_tkb_f8_10((int)c.QK, la.kmajor, lb.kmajor, p, st) : gnk_launch_tkb_f8_11((int)c.QK, la.kmajor, lb.kmajor, p, st);
     }
+    if (variant == GNK_VARIANT_64X128 && op == OP_F8) return gnk_launch_f8_v6(fa, fb, la.kmajor, lb.kmajor, c.epi, p, st);
     return pick_launcher(op, fa, fb, variant)(la.kmajor, lb.kmajor, c.epi, p, st);
 }
 

@@ -13,7 +13,7 @@
 //   4: 256 x 256 tile, 8 waves, two 128-k buffers, 8-phase ping-pong (gnk_gemm_pp.h): int8, and fp8 on the 16x16x128 MFMA;
 //      the heuristic's choice whenever A is K-major (A@B.T, A@B)
 //   5: 256 x 256 tile, 4 waves (one per SIMD, 128 x 128 wave tile), four 64-k stages, one barrier per stage (gnk_gemm_w4.h)
-//   6: 64 x 128 tile, 4 waves (2 x 2, 32 x 64 wave tiles), two-buffer loop, 48 KiB LDS: int8 plain / row-col products whose 128 x 128 tiling
+//   6: 64 x 128 tile, 4 waves (2 x 2, 32 x 64 wave tiles), two-buffer loop, 48 KiB LDS: int8 / fp8 plain / row-col products whose 128 x 128 tiling
 //      would put at most one workgroup on a CU (mid sizes, grad-weights of narrow Linears) -- twice the workgroups, two instruction streams per SIMD
 enum { GNK_VARIANT_256 = 0, GNK_VARIANT_128 = 1, GNK_VARIANT_GENERIC = 2, GNK_VARIANT_256_SIMPLE = 3, GNK_VARIANT_256_PP8 = 4, GNK_VARIANT_256_W4 = 5,
        GNK_VARIANT_64X128 = 6, GNK_VARIANT_LAST = 6,
@@ -37,6 +37,7 @@ GNK_DECLARE_LAUNCHER(gnk_launch_f8_10_v4);
 GNK_DECLARE_LAUNCHER(gnk_launch_f8_11_v4);
 GNK_DECLARE_LAUNCHER(gnk_launch_i8_v5);
 GNK_DECLARE_LAUNCHER(gnk_launch_i8_v6);
+int gnk_launch_f8_v6(int fa, int fb, bool a_kmajor, bool b_kmajor, int epi, const GemmParams &p, hipStream_t st);
 GNK_DECLARE_LAUNCHER(gnk_launch_f8_00_v5);
 GNK_DECLARE_LAUNCHER(gnk_launch_f8_01_v5);
 GNK_DECLARE_LAUNCHER(gnk_launch_f8_10_v5);
