@@ -43,7 +43,7 @@ typedef enum gnk_status {
  * the meaning of an argument or return code (kernel changes behind an unchanged signature do not count); a binding compares
  * gnk_abi_version() of the loaded library with the GNK_ABI_VERSION it was written against and refuses a mismatch.
  *   1: round 1.   2: rounds 2-3 -- gnk_scaled_mm_ws / gnk_scaled_mm_t, the fused quantize pair, gnk_quantize_int8_noalloc, the MX and BitNet
- *      entry points added; gnk_set_debug_flags removed from the shipped library; gnk_set_gemm_variant accepts 5 and -2; gnk_set_tile_rescale added. */
+ *      entry points added; gnk_set_debug_flags removed from the shipped library; gnk_set_gemm_variant accepts 5, 6, -2 and -3; gnk_set_tile_rescale added. */
 #define GNK_ABI_VERSION 2
 int gnk_abi_version(void);
 
