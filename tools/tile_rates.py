@@ -11,6 +11,10 @@ import bench
 import gn_kernels
 
 S = 4096
+import os
+if os.environ.get("GNK_VARIANT"):       # force a tile variant (csrc/gnk_gemm_dispatch.h), e.g. 6 = 64 x 128 tiles
+    from gn_kernels import _cabi
+    _cabi.load().gnk_set_gemm_variant(int(os.environ["GNK_VARIANT"]))
 lay = lambda x, cm: x.T.contiguous().T if cm else x.contiguous()
 for kind in ("i8", "f8"):
     for blk in (128, 32):
